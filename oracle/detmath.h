@@ -1,0 +1,384 @@
+/*
+ * oracle/detmath.h -- TEST INFRASTRUCTURE (parity oracle), not product code.
+ *
+ * Deterministic double-precision elementary functions used by the CPU restatement
+ * (oracle/tpg_oracle.c) of CliMA/OrthogonalSphericalShellGrids.jl's TripolarGrid path.
+ *
+ * Why this exists: the reference is Julia; its arithmetic calls Julia Base (sind, cosd, tand,
+ * asinh, sinh, cosh, atan, sin, cos, asin, sqrt, rem) -- third-party to /root/reference, source
+ * absent from this container, no Julia toolchain.  Julia Base implements these as ports of the
+ * FreeBSD msun algorithms (k_sin/k_cos/e_rem_pio2/s_atan/e_asin) plus degree-exact argument
+ * reduction for the *d functions.  This header restates those PUBLISHED algorithms using only
+ * IEEE-754 correctly-rounded primitives (+ - * / sqrt fma, integer/bit operations), so that the
+ * same operation sequence -- restated independently in the product's device code -- yields
+ * bit-identical results on x86-64 and on gfx950.  ("parity unpinned" beyond the reference's own
+ * 6-digit README transcript: see DESIGN.md.)
+ *
+ * Everything must be compiled with -ffp-contract=off; fused operations are written as fma().
+ *
+ * Semantics that the reference relies on:
+ *   sind(+-180) = +-0, sind(0) = 0, cosd(+-90) = +0, sind(+-90) = +-1, tand = sind/cosd,
+ *   atan(+-Inf) = +-pi/2, signed zeros preserved through division.
+ */
+#ifndef TPG_ORACLE_DETMATH_H
+#define TPG_ORACLE_DETMATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define DM_INLINE static inline
+
+/* ---------------------------------------------------------------- constants (gen_constants.py) */
+#define DM_PI        0x1.921fb54442d18p+1
+#define DM_DEG2RAD   0x1.1df46a2529d39p-6   /* Float64(pi)/180, Julia deg2rad */
+#define DM_D2R_LO    0x1.5c1d8becdd291p-62  /* pi/180 - DM_DEG2RAD */
+#define DM_INVPIO2   0x1.45f306dc9c883p-1
+#define DM_PIO2_1    0x1.921fb54400000p+0
+#define DM_PIO2_1T   0x1.0b4611a626331p-34
+#define DM_PIO2_2    0x1.0b4611a600000p-34
+#define DM_PIO2_2T   0x1.3198a2e037073p-69
+#define DM_PIO2_3    0x1.3198a2e000000p-69
+#define DM_PIO2_3T   0x1.b839a252049c1p-104
+#define DM_PIO2_HI   0x1.921fb54442d18p+0
+#define DM_PIO2_LO   0x1.1a62633145c07p-54
+#define DM_PIO4_HI   0x1.921fb54442d18p-1
+#define DM_LN2_HI    0x1.62e42fefa39efp-1
+#define DM_LN2_LO    0x1.abc9e3b39803fp-56
+
+DM_INLINE uint64_t dm_bits(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+DM_INLINE double dm_from_bits(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+DM_INLINE int dm_exponent(double x) { return (int)((dm_bits(x) >> 52) & 0x7ff); }
+
+/* ---------------------------------------------------------------- sin / cos kernels on [-pi/4, pi/4]
+ * FreeBSD msun k_sin.c / k_cos.c (the kernels Julia Base's sin_kernel/cos_kernel port);
+ * argument is the double-double x + y, |y| << |x|.  Horner form with explicit fma. */
+DM_INLINE double dm_ksin(double x, double y)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = x * x;
+    double r = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+    double v = z * x;
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+
+DM_INLINE double dm_kcos(double x, double y)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = x * x;
+    double r = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    double hz = 0.5 * z;
+    double w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+
+/* ---------------------------------------------------------------- radian sin / cos
+ * msun e_rem_pio2.c "medium" path (Cody-Waite, up to 3 iterations); valid for |x| < 2^20*pi/2,
+ * far beyond what haversine / the lat-lon continuation ever pass (|x| <= ~pi). */
+DM_INLINE int dm_rem_pio2(double x, double *y0, double *y1)
+{
+    double fn = rint(x * DM_INVPIO2);
+    int n = (int)fn;
+    double r = x - fn * DM_PIO2_1;
+    double w = fn * DM_PIO2_1T;
+    int j = dm_exponent(x);
+    double a = r - w;
+    if (j - dm_exponent(a) > 16) {
+        double t = r;
+        w = fn * DM_PIO2_2;
+        r = t - w;
+        w = fn * DM_PIO2_2T - ((t - r) - w);
+        a = r - w;
+        if (j - dm_exponent(a) > 49) {
+            t = r;
+            w = fn * DM_PIO2_3;
+            r = t - w;
+            w = fn * DM_PIO2_3T - ((t - r) - w);
+            a = r - w;
+        }
+    }
+    *y0 = a;
+    *y1 = (r - a) - w;
+    return n;
+}
+
+DM_INLINE double dm_sin(double x)
+{
+    if (!(fabs(x) <= 0x1.921fb54442d18p-1)) {          /* |x| > pi/4 */
+        double y0, y1;
+        int n = dm_rem_pio2(x, &y0, &y1);
+        switch (n & 3) {
+        case 0:  return dm_ksin(y0, y1);
+        case 1:  return dm_kcos(y0, y1);
+        case 2:  return -dm_ksin(y0, y1);
+        default: return -dm_kcos(y0, y1);
+        }
+    }
+    if (dm_exponent(x) < 0x3e5) return x;               /* |x| < 2^-26 */
+    return dm_ksin(x, 0.0);
+}
+
+DM_INLINE double dm_cos(double x)
+{
+    if (!(fabs(x) <= 0x1.921fb54442d18p-1)) {
+        double y0, y1;
+        int n = dm_rem_pio2(x, &y0, &y1);
+        switch (n & 3) {
+        case 0:  return dm_kcos(y0, y1);
+        case 1:  return -dm_ksin(y0, y1);
+        case 2:  return -dm_kcos(y0, y1);
+        default: return dm_ksin(y0, y1);
+        }
+    }
+    return dm_kcos(x, 0.0);
+}
+
+/* ---------------------------------------------------------------- degree trig (Julia sind/cosd)
+ * Exact reduction in degrees (rem(x,360)), octant selection, then the radian kernels on a
+ * double-double deg->rad product.  Exact zeros / ones at multiples of 90 as Julia Base returns. */
+DM_INLINE void dm_deg2rad_ext(double x, double *hi, double *lo)
+{
+    double h = x * DM_DEG2RAD;
+    *lo = fma(x, DM_DEG2RAD, -h) + x * DM_D2R_LO;
+    *hi = h;
+}
+
+DM_INLINE double dm_sind(double x)
+{
+    double rx = copysign(fmod(x, 360.0), x);
+    double arx = fabs(rx);
+    double h, l;
+    if (rx == 0.0) return rx;
+    if (arx < 45.0) { dm_deg2rad_ext(rx, &h, &l); return dm_ksin(h, l); }
+    if (arx <= 135.0) { dm_deg2rad_ext(90.0 - arx, &h, &l); return copysign(dm_kcos(h, l), rx); }
+    if (arx == 180.0) return copysign(0.0, rx);
+    if (arx < 225.0) { dm_deg2rad_ext((180.0 - arx) * copysign(1.0, rx), &h, &l); return dm_ksin(h, l); }
+    if (arx <= 315.0) { dm_deg2rad_ext(270.0 - arx, &h, &l); return -copysign(dm_kcos(h, l), rx); }
+    dm_deg2rad_ext(rx - copysign(360.0, rx), &h, &l);
+    return dm_ksin(h, l);
+}
+
+DM_INLINE double dm_cosd(double x)
+{
+    double rx = fabs(fmod(x, 360.0));
+    double h, l;
+    if (rx <= 45.0) { dm_deg2rad_ext(rx, &h, &l); return dm_kcos(h, l); }
+    if (rx < 135.0) { dm_deg2rad_ext(90.0 - rx, &h, &l); return dm_ksin(h, l); }
+    if (rx <= 225.0) { dm_deg2rad_ext(180.0 - rx, &h, &l); return -dm_kcos(h, l); }
+    if (rx < 315.0) { dm_deg2rad_ext(rx - 270.0, &h, &l); return dm_ksin(h, l); }
+    dm_deg2rad_ext(360.0 - rx, &h, &l);
+    return dm_kcos(h, l);
+}
+
+DM_INLINE double dm_tand(double x) { return dm_sind(x) / dm_cosd(x); }
+
+/* ---------------------------------------------------------------- atan (msun s_atan.c) */
+DM_INLINE double dm_atan(double x)
+{
+    static const double aT[11] = {
+        3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01,
+        -1.11111104054623557880e-01, 9.09088713343650656196e-02, -7.69187620504482999495e-02,
+        6.66107313738753120669e-02, -5.83357013379057348645e-02, 4.97687799461593236017e-02,
+        -3.65315727442169155270e-02, 1.62858201153657823623e-02 };
+    static const double hi[4] = { 0x1.dac670561bb4fp-2, 0x1.921fb54442d18p-1,
+                                  0x1.f730bd281f69bp-1, 0x1.921fb54442d18p+0 };
+    static const double lo[4] = { 0x1.a2b7f222f65e2p-56, 0x1.1a62633145c07p-55,
+                                  0x1.007887af0cbbdp-56, 0x1.1a62633145c07p-54 };
+    double ax = fabs(x);
+    int id;
+    double t;
+    if (x != x) return x;
+    if (ax >= 0x1p66) return copysign(hi[3] + lo[3], x);
+    if (ax < 0.4375) {
+        if (ax < 0x1p-27) return x;
+        id = -1; t = ax;
+    } else if (ax < 1.1875) {
+        if (ax < 0.6875) { id = 0; t = (2.0 * ax - 1.0) / (2.0 + ax); }
+        else             { id = 1; t = (ax - 1.0) / (ax + 1.0); }
+    } else {
+        if (ax < 2.4375) { id = 2; t = (ax - 1.5) / (1.0 + 1.5 * ax); }
+        else             { id = 3; t = -1.0 / ax; }
+    }
+    double z = t * t;
+    double w = z * z;
+    double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, aT[10], aT[8]), aT[6]), aT[4]), aT[2]), aT[0]);
+    double s2 = w * fma(w, fma(w, fma(w, fma(w, aT[9], aT[7]), aT[5]), aT[3]), aT[1]);
+    double r;
+    if (id < 0) r = t - t * (s1 + s2);
+    else        r = hi[id] - ((t * (s1 + s2) - lo[id]) - t);
+    return copysign(r, x);
+}
+
+/* ---------------------------------------------------------------- asin (msun e_asin.c) */
+DM_INLINE double dm_asin_pq(double t)
+{
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
+                 pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+                 pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
+                 qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+    double p = t * fma(t, fma(t, fma(t, fma(t, fma(t, pS5, pS4), pS3), pS2), pS1), pS0);
+    double q = fma(t, fma(t, fma(t, fma(t, qS4, qS3), qS2), qS1), 1.0);
+    return p / q;
+}
+
+DM_INLINE double dm_asin(double x)
+{
+    double ax = fabs(x);
+    if (ax >= 1.0) {
+        if (ax == 1.0) return x * DM_PIO2_HI + x * DM_PIO2_LO;
+        return (x - x) / (x - x);                         /* NaN */
+    }
+    if (ax < 0.5) {
+        if (ax < 0x1p-26) return x;
+        return x + x * dm_asin_pq(x * x);
+    }
+    double w = 1.0 - ax;
+    double t = w * 0.5;
+    double r = dm_asin_pq(t);
+    double s = sqrt(t);
+    double res;
+    if (ax >= 0.975) {
+        res = DM_PIO2_HI - (2.0 * (s + s * r) - DM_PIO2_LO);
+    } else {
+        double f = dm_from_bits(dm_bits(s) & 0xffffffff00000000ull);
+        double c = (t - f * f) / (s + f);
+        double p = 2.0 * s * r - (DM_PIO2_LO - 2.0 * c);
+        double q = DM_PIO4_HI - 2.0 * f;
+        res = DM_PIO4_HI - (p - q);
+    }
+    return copysign(res, x);
+}
+
+/* ---------------------------------------------------------------- double-double toolkit
+ * Used only for the O(Nphi) latitude-stretching table (asinh, sinh, cosh), where a result
+ * correct to ~100 bits and then rounded once is the best available stand-in for Julia Base's
+ * <1 ulp asinh/sinh/cosh. */
+typedef struct { double hi, lo; } dm_dd;
+
+DM_INLINE dm_dd dm_dd_make(double hi, double lo) { dm_dd r; r.hi = hi; r.lo = lo; return r; }
+DM_INLINE dm_dd dm_two_sum(double a, double b)
+{
+    double s = a + b, bb = s - a;
+    return dm_dd_make(s, (a - (s - bb)) + (b - bb));
+}
+DM_INLINE dm_dd dm_quick_two_sum(double a, double b)
+{
+    double s = a + b;
+    return dm_dd_make(s, b - (s - a));
+}
+DM_INLINE dm_dd dm_two_prod(double a, double b)
+{
+    double p = a * b;
+    return dm_dd_make(p, fma(a, b, -p));
+}
+DM_INLINE dm_dd dm_dd_add(dm_dd a, dm_dd b)
+{
+    dm_dd s = dm_two_sum(a.hi, b.hi), t = dm_two_sum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = dm_quick_two_sum(s.hi, s.lo);
+    s.lo += t.lo;
+    return dm_quick_two_sum(s.hi, s.lo);
+}
+DM_INLINE dm_dd dm_dd_neg(dm_dd a) { return dm_dd_make(-a.hi, -a.lo); }
+DM_INLINE dm_dd dm_dd_sub(dm_dd a, dm_dd b) { return dm_dd_add(a, dm_dd_neg(b)); }
+DM_INLINE dm_dd dm_dd_mul(dm_dd a, dm_dd b)
+{
+    dm_dd p = dm_two_prod(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return dm_quick_two_sum(p.hi, p.lo);
+}
+DM_INLINE dm_dd dm_dd_mul_d(dm_dd a, double b)
+{
+    dm_dd p = dm_two_prod(a.hi, b);
+    p.lo += a.lo * b;
+    return dm_quick_two_sum(p.hi, p.lo);
+}
+DM_INLINE dm_dd dm_dd_div(dm_dd a, dm_dd b)
+{
+    double q1 = a.hi / b.hi;
+    dm_dd r = dm_dd_sub(a, dm_dd_mul_d(b, q1));
+    double q2 = r.hi / b.hi;
+    r = dm_dd_sub(r, dm_dd_mul_d(b, q2));
+    double q3 = r.hi / b.hi;
+    dm_dd q = dm_quick_two_sum(q1, q2);
+    return dm_dd_add(q, dm_dd_make(q3, 0.0));
+}
+DM_INLINE dm_dd dm_dd_sqrt(dm_dd a)
+{
+    if (a.hi <= 0.0) return dm_dd_make(0.0, 0.0);
+    double x = 1.0 / sqrt(a.hi);
+    double ax = a.hi * x;
+    dm_dd e = dm_dd_sub(a, dm_two_prod(ax, ax));
+    return dm_two_sum(ax, e.hi * (x * 0.5));
+}
+/* exp(a) - 1 and the binary exponent k such that exp(a) = (1 + s) * 2^k;  |a.hi| < ~700 */
+DM_INLINE dm_dd dm_dd_expm1_reduced(dm_dd a, int *kout)
+{
+    const dm_dd ln2 = { DM_LN2_HI, DM_LN2_LO };
+    double kf = rint(a.hi / DM_LN2_HI);
+    dm_dd r = dm_dd_sub(a, dm_dd_mul_d(ln2, kf));
+    r.hi *= 0x1p-9; r.lo *= 0x1p-9;                      /* r / 512, exact */
+    /* Taylor: s = r + r^2/2! + ... + r^11/11!  (|r| < 7e-4 -> truncation < 1e-40) */
+    dm_dd term = r, s = r;
+    for (int n = 2; n <= 11; ++n) {
+        term = dm_dd_mul(term, r);
+        term = dm_dd_div(term, dm_dd_make((double)n, 0.0));
+        s = dm_dd_add(s, term);
+    }
+    for (int i = 0; i < 9; ++i)                          /* (1+s)^2 - 1 = 2s + s^2 */
+        s = dm_dd_add(dm_dd_mul_d(s, 2.0), dm_dd_mul(s, s));
+    *kout = (int)kf;
+    return s;
+}
+DM_INLINE dm_dd dm_dd_exp(dm_dd a)
+{
+    int k;
+    dm_dd s = dm_dd_expm1_reduced(a, &k);
+    dm_dd e = dm_dd_add(dm_dd_make(1.0, 0.0), s);
+    double sc = dm_from_bits((uint64_t)(1023 + k) << 52);
+    e.hi *= sc; e.lo *= sc;
+    return e;
+}
+/* log(a), a > 0: deterministic seed (atanh series in double), then 3 Newton steps in dd */
+DM_INLINE dm_dd dm_dd_log(dm_dd a)
+{
+    int e = dm_exponent(a.hi) - 1023;
+    double m = dm_from_bits((dm_bits(a.hi) & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    if (m > 0x1.6a09e667f3bcdp+0) { m *= 0.5; e += 1; }  /* m in (sqrt(1/2), sqrt(2)] */
+    double u = (m - 1.0) / (m + 1.0), u2 = u * u;
+    double ser = u * (2.0 + u2 * (2.0 / 3.0 + u2 * (2.0 / 5.0 + u2 * (2.0 / 7.0 + u2 * (2.0 / 9.0
+                 + u2 * (2.0 / 11.0 + u2 * (2.0 / 13.0)))))));
+    dm_dd y = dm_two_sum((double)e * DM_LN2_HI, ser);
+    for (int it = 0; it < 3; ++it) {                     /* y <- y + a*exp(-y) - 1 */
+        dm_dd ey = dm_dd_exp(dm_dd_neg(y));
+        dm_dd c = dm_dd_sub(dm_dd_mul(a, ey), dm_dd_make(1.0, 0.0));
+        y = dm_dd_add(y, c);
+    }
+    return y;
+}
+
+DM_INLINE double dm_asinh(double x)
+{
+    double ax = fabs(x);
+    if (ax == 0.0 || x != x) return x;
+    dm_dd a = dm_dd_make(ax, 0.0);
+    dm_dd s = dm_dd_sqrt(dm_dd_add(dm_two_prod(ax, ax), dm_dd_make(1.0, 0.0)));
+    dm_dd l = dm_dd_log(dm_dd_add(a, s));
+    return copysign(l.hi + l.lo, x);
+}
+DM_INLINE void dm_sinh_cosh(double x, double *sh, double *ch)
+{
+    double ax = fabs(x);
+    dm_dd e = dm_dd_exp(dm_dd_make(ax, 0.0));
+    dm_dd ie = dm_dd_div(dm_dd_make(1.0, 0.0), e);
+    dm_dd s = dm_dd_sub(e, ie), c = dm_dd_add(e, ie);
+    *sh = copysign(0.5 * (s.hi + s.lo), x);
+    *ch = 0.5 * (c.hi + c.lo);
+}
+
+#endif /* TPG_ORACLE_DETMATH_H */
