@@ -1,0 +1,153 @@
+/*
+ * tripolar_hip.h -- C ABI of libtripolar_hip.so: MI355X (gfx950) implementation of the
+ * TripolarGrid metric precompute and Zipper halo fill of CliMA/OrthogonalSphericalShellGrids.jl.
+ *
+ * The reference has no FFI of its own (pure Julia, multiple dispatch on Oceananigans generics,
+ * SURVEY.md 8b).  Each entry point below names the reference interface it replaces
+ * (file:line under the reference tree); INTEGRATION.md shows the Julia `ccall` methods a
+ * maintainer would add so that Oceananigans keeps seeing TripolarGrid() /
+ * ZipperBoundaryCondition / fill_halo_regions!.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only; no exceptions cross the boundary.
+ *  - every call returns TPG_OK (0), a negative tpg_status, or a positive hipError_t;
+ *    tpg_last_error() returns a thread-local message for the last failure on this thread.
+ *  - all array memory is DEVICE memory owned by the caller (Julia GC / torch); the library
+ *    never allocates or frees device memory and keeps no reference past stream completion.
+ *  - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *    re-entrant, graph-capturable, thread-safe for distinct streams.
+ *  - array layout: column-major padded parent arrays, i fastest:
+ *      2-D  A[i,j]   at  (i+Hx-1) + (Nx+2Hx) * (j+Hy-1)
+ *      3-D  c[i,j,k] at  (i+Hx-1) + (Nx+2Hx) * ((j+Hy-1) + (Ny+2Hy) * (k+Hz-1))
+ *    i.e. exactly the `parent` of Oceananigans' OffsetArrays.
+ *  - element type selected by `ft`: TPG_F32 or TPG_F64.
+ */
+#ifndef TRIPOLAR_HIP_H
+#define TRIPOLAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPG_VERSION 100 /* 0.1.0 */
+
+enum tpg_status {
+    TPG_OK = 0,
+    TPG_ERR_INVALID_ARGUMENT = -1, /* null pointer, negative size, unknown ft/location ...        */
+    TPG_ERR_ODD_NLAMBDA = -2,      /* ArgumentError of src/tripolar_grid.jl:81-83                 */
+    TPG_ERR_BAD_PARTITION = -3,    /* row band outside 1..Ny (src/distributed_tripolar_grid.jl:28-49) */
+    TPG_ERR_WORKSPACE = -4,        /* workspace missing or too small                              */
+    TPG_ERR_UNSUPPORTED = -5,      /* size outside what the kernels index (see tpg_limits)        */
+    TPG_ERR_NOT_NORTH = -6         /* zipper requested on a non-north side
+                                      (src/zipper_boundary_condition.jl:58-62)                    */
+};
+
+enum tpg_ft { TPG_F32 = 0, TPG_F64 = 1 };
+enum tpg_loc { TPG_CENTER = 0, TPG_FACE = 1 };
+
+/* Order of the 20 horizontal arrays = positional order of src/tripolar_grid.jl:308-328
+ * (z is 1-D and stays with the host glue).  Note the dy order: cc, cf, fc, ff. */
+enum tpg_array {
+    TPG_LAMBDA_CC = 0, TPG_LAMBDA_FC, TPG_LAMBDA_CF, TPG_LAMBDA_FF,
+    TPG_PHI_CC, TPG_PHI_FC, TPG_PHI_CF, TPG_PHI_FF,
+    TPG_DX_CC, TPG_DX_FC, TPG_DX_CF, TPG_DX_FF,
+    TPG_DY_CC, TPG_DY_CF, TPG_DY_FC, TPG_DY_FF,
+    TPG_AZ_CC, TPG_AZ_FC, TPG_AZ_CF, TPG_AZ_FF,
+    TPG_NUM_ARRAYS
+};
+
+/* Keyword arguments of TripolarGrid(arch, FT; size, southernmost_latitude, halo, radius,
+ * north_poles_latitude, first_pole_longitude)  (src/tripolar_grid.jl:59-66), plus the latitude
+ * band of src/distributed_tripolar_grid.jl:47-49 (serial grid: jstart = 1, jend = Ny). */
+typedef struct tpg_params {
+    int32_t Nx, Ny, Nz;           /* size = (Nlambda, Nphi, Nz) of the GLOBAL grid                */
+    int32_t Hx, Hy, Hz;           /* halo                                                         */
+    double southernmost_latitude; /* default -80                                                  */
+    double north_poles_latitude;  /* default  55                                                  */
+    double first_pole_longitude;  /* default  70                                                  */
+    double radius;                /* default R_Earth = 6371e3                                     */
+    int32_t ft;                   /* enum tpg_ft: element type of the 20 output arrays            */
+    int32_t jstart;               /* first global row owned by this rank (1-based)                */
+    int32_t jend;                 /* last global row owned by this rank (== Ny on the north rank) */
+    int32_t reserved;             /* must be 0                                                    */
+} tpg_params;
+
+int tpg_version(void);
+const char *tpg_last_error(void);
+const char *tpg_status_string(int status);
+
+/* ---- metric precompute ------------------------------------------------------------------
+ * Replaces, in one call, src/tripolar_grid.jl:73-328: the 1-D tables (:76-97),
+ * _compute_tripolar_coordinates! (src/generate_tripolar_coordinates.jl:53-89) + circshift
+ * (:121-130) + coordinate halo fill (:137-199), _calculate_metrics!
+ * (src/tripolar_grid_utils.jl:4-45), the 12 metric halo fills (:230-273), continue_south!
+ * (:277-300, :336-357) and map(FT, .) (:308-328); with jstart/jend it also replaces the
+ * per-rank slicing of src/distributed_tripolar_grid.jl:36-73 without building the globe.
+ *
+ * out[q] (q = enum tpg_array): device array of (Nx+2Hx) x (jend-jstart+1+2Hy) elements of `ft`;
+ * local row r (0-based) holds global row jstart-Hy+r.
+ * workspace: device scratch of at least tpg_build_grid_workspace_bytes(p) bytes, 16-B aligned.
+ */
+size_t tpg_build_grid_workspace_bytes(const tpg_params *p);
+int tpg_build_grid(const tpg_params *p, void *const out[TPG_NUM_ARRAYS],
+                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- zipper halo fill -------------------------------------------------------------------
+ * Replaces Oceananigans' south/north halo kernel when the north BC is a ZipperBoundaryCondition:
+ * _fill_north_halo!(i, k, grid, c, bc::ZBC, loc, args...) for every (i,k)
+ * (src/zipper_boundary_condition.jl:146-155), i.e. fold_north_{center_center,face_center,
+ * center_face,face_face}! (:70-138), dispatched on (xloc[f], yloc[f]); sign[f] is bc.condition
+ * (ZipperBoundaryCondition(sign), :52).  All `nfields` fields share one geometry and are folded
+ * by ONE kernel launch (batched pointer table, up to TPG_MAX_FIELDS per launch; more are split).
+ * Levels k = kstart .. kstart+kcount-1 (1-based, may include halo levels 1-Hz..Nz+Hz).
+ * In place; halo columns i<1, i>Nx are left to the periodic pass, as in the reference.
+ */
+#define TPG_MAX_FIELDS 16
+int tpg_zipper_fill(void *const fields[], int nfields,
+                    const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                    int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
+                    int kstart, int kcount, int ft, void *stream);
+
+/* Oceananigans' periodic west/east halo fill, which fill_halo_regions! runs AFTER the zipper
+ * (pinned by test/test_zipper_boundary_conditions.jl:42-45): every row and level of the parent. */
+int tpg_periodic_x_fill(void *const fields[], int nfields,
+                        int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
+
+/* fill_halo_regions!(field) on a (Periodic, RightConnected, *) tripolar field: zipper on
+ * k = 1..Nz if `north_is_zipper` (serial grid, or last rank: src/distributed_tripolar_grid.jl:
+ * 143-147,177-185), then periodic x. */
+int tpg_fill_halo_regions(void *const fields[], int nfields,
+                          const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                          int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
+                          int north_is_zipper, int ft, void *stream);
+
+/* ---- latitude-band halo exchange helpers (config 4) -------------------------------------
+ * The interior seams of a y-slab partition exchange Hy full rows (all i incl. x halos, all
+ * levels incl. z halos) per side and field; the transport (RCCL send/recv, ROCm-aware MPI) stays
+ * with the host, as it does in the reference (Oceananigans DistributedComputations, reached from
+ * src/distributed_tripolar_grid.jl:171,195).  These two kernels gather / scatter the rows
+ * between the padded 3-D fields and one contiguous message buffer of
+ * nfields * (Nx+2Hx) * Hy * (Nz+2Hz) elements.
+ * side: 0 = south, 1 = north.  pack reads the INTERIOR rows adjacent to that side
+ * (south: j = 1..Hy, north: j = Ny-Hy+1..Ny); unpack writes the HALO rows of that side
+ * (south: j = 1-Hy..0, north: j = Ny+1..Ny+Hy).
+ */
+size_t tpg_y_halo_buffer_elems(int nfields, int Nx, int Nz, int Hx, int Hy, int Hz);
+int tpg_pack_y_halo(void *const fields[], int nfields, void *buffer, int side,
+                    int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
+int tpg_unpack_y_halo(void *const fields[], int nfields, const void *buffer, int side,
+                      int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
+
+/* Deterministic synthetic field fill used by tests and bench.py:
+ * interior (i,j,k) gets a splitmix64(seed, linear index) value in (-1,1); every halo cell gets
+ * `halo_sentinel`.  Not part of the reference surface. */
+int tpg_fill_synthetic(void *field, uint64_t seed, double halo_sentinel,
+                       int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRIPOLAR_HIP_H */

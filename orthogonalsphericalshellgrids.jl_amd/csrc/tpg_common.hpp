@@ -1,0 +1,45 @@
+// tpg_common.hpp -- shared host-side helpers of libtripolar_hip (error channel, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/tripolar_hip.h"
+
+namespace tpg {
+
+void set_error(const char* fmt, ...);
+
+// returns a C-ABI status from a HIP error (positive hipError_t) and records the message
+inline int hip_status(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return TPG_OK;
+    set_error("%s: %s (hipError_t %d)", what, hipGetErrorString(e), (int)e);
+    return (int)e;
+}
+
+inline int launch_status(const char* kernel)
+{
+    return hip_status(hipGetLastError(), kernel);
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// geometry of one padded 3-D field (or 2-D with Nz = 1, Hz = 0)
+struct Geom {
+    int Nx, Ny, Nz, Hx, Hy, Hz;
+    int sx;          // Nx + 2Hx
+    int sy;          // Ny + 2Hy
+    long long plane; // sx * sy
+};
+
+inline Geom make_geom(int Nx, int Ny, int Nz, int Hx, int Hy, int Hz)
+{
+    Geom g{ Nx, Ny, Nz, Hx, Hy, Hz, Nx + 2 * Hx, Ny + 2 * Hy, 0 };
+    g.plane = (long long)g.sx * g.sy;
+    return g;
+}
+
+int check_geom(int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft);
+
+}  // namespace tpg

@@ -1,0 +1,459 @@
+// tpg_grid.hip -- TripolarGrid coordinate + staggered-metric precompute for gfx950.
+//
+// Replaces src/tripolar_grid.jl:73-328 of the reference (see include/tripolar_hip.h).  The
+// reference runs ~40 full-array host passes (two CPU KernelAbstractions kernels, 8 circshifts,
+// 20 Field set!/fill_halo_regions!/deepcopy round trips, 12 continue_south!, 20 map+H2D copies);
+// here the final padded device arrays are produced directly by four launches on one stream:
+//
+//   K0 tables      : per-i  a*sind(lambda), a*cosd(lambda) (Face, Center; the Nlambda/4 circshift is
+//                    folded into the index), per-j sinh(psi), cosh(psi) latitude-stretching tables
+//                    (Face, Center), and the (Hy+1)-row lat-lon continuation table.  O(Nx+Ny) work.
+//   K1 cells       : one thread per interior cell (i, j) of the rank's row band: evaluates the
+//                    Murray (1996) map at the 4 staggered locations of the cell and of its stencil
+//                    neighbours THROUGH the halo index maps (periodic x, zipper fold, row-Ny
+//                    substitution, zero south halo), then the 8 haversine edge lengths, 2
+//                    spherical quadrilateral areas and 2 product areas; stores 8 + 12 values.
+//   K2 halos       : compact pass over halo cells only (x-halo columns, north fold rows, zero
+//                    south rows of the coordinates, row-Ny substitution of the y-Center metrics).
+//   K3 south       : lat-lon continuation rows j = 1-Hy..1 of the 12 metrics (south rank only).
+//
+// No inter-rank communication: seam halo rows are the neighbour's interior rows of the same
+// analytic function.
+#include "tpg_common.hpp"
+#include "tpg_math.hpp"
+
+using namespace tpgm;
+
+namespace {
+
+constexpr double kC180Pi = 180.0 / kPi;
+constexpr double kC360Pi = 360.0 / kPi;
+
+struct GridK {
+    int Nx, Ny, Hx, Hy;
+    int shift;            // Nx / 4
+    int jstart, jend;     // owned global rows
+    int jm_lo, jm_hi;     // global rows whose interior cells this rank evaluates
+    int sx, rows;         // local padded extents
+    int ft;
+    double fplp90;        // first_pole_longitude + 90
+    double R;
+    // workspace tables
+    const double* ti;     // [4][Nx]: a*sind(lf), a*cosd(lf), a*sind(lc), a*cosd(lc), post-shift index
+    const double* tj;     // [4][Ny]: sinh/cosh(psi) at Face rows, then at Center rows
+    const double* ts;     // [5][Hy+1]: dx_c, dx_f, az_c, az_f, dy for j = 1-Hy..1
+};
+
+struct OutPtrs { void* p[TPG_NUM_ARRAYS]; };
+
+struct TableArgs {
+    int Nx, Ny, Hy, shift, ft;
+    double south, npl, R;
+    double* ti; double* tj; double* ts;
+};
+
+// ---- 1-D tables (src/tripolar_grid.jl:76-97) ------------------------------------------------
+__device__ double lambda_face(int i, int N, int ft)
+{
+    long long num = 360ll * (i - 1) - 180ll * N;
+    if (ft == TPG_F32) return (double)((float)num / (float)N);
+    return (double)num / (double)N;
+}
+__device__ double lambda_center(int i, int N, int ft)
+{
+    long long num = 360ll * (2ll * i - 1) - 360ll * N;
+    if (ft == TPG_F32) return (double)((float)num / (float)(2ll * N));
+    return (double)num / (double)(2ll * N);
+}
+__device__ double phi_center(int j, int N, double south)
+{
+    if (N == 1) return south;
+    if (south == __builtin_rint(south) && absD(south) < 1e6) {
+        long long s = (long long)south;
+        long long num = s * (N - 1) + (90 - s) * (long long)(j - 1);
+        return (double)num / (double)(N - 1);
+    }
+    dd step = dd_div(two_sum(90.0, -south), dd{ (double)(N - 1), 0.0 });
+    dd v = dd_add(dd{ south, 0.0 }, dd_mul_d(step, (double)(j - 1)));
+    return v.hi + v.lo;
+}
+
+__global__ __launch_bounds__(64) void k_tables(TableArgs t)
+{
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const double a = tand((90.0 - t.npl) / 2);               // focal_distance, :76
+    if (tid < t.Nx) {
+        int is = tid + 1;
+        int i0 = is - t.shift; if (i0 < 1) i0 += t.Nx;        // circshift folded into the index (:121-130)
+        double lf = lambda_face(i0, t.Nx, t.ft), lc = lambda_center(i0, t.Nx, t.ft);
+        double slf = sind(lf), clf = cosd(lf), slc = sind(lc), clc = cosd(lc);
+        if (t.ft == TPG_F32) {   // sind(::Float32) returns Float32 in the reference
+            slf = (double)(float)slf; clf = (double)(float)clf; slc = (double)(float)slc; clc = (double)(float)clc;
+        }
+        t.ti[0 * t.Nx + tid] = a * slf;
+        t.ti[1 * t.Nx + tid] = a * clf;
+        t.ti[2 * t.Nx + tid] = a * slc;
+        t.ti[3 * t.Nx + tid] = a * clc;
+        return;
+    }
+    tid -= t.Nx;
+    if (tid < 2 * t.Ny) {
+        int face = tid < t.Ny;
+        int j = (face ? tid : tid - t.Ny) + 1;
+        double pc = phi_center(j, t.Ny, t.south);
+        double phi = pc;
+        if (face) {
+            double dphi = t.Ny > 1 ? phi_center(2, t.Ny, t.south) - phi_center(1, t.Ny, t.south) : 0.0;   // :96
+            phi = pc - dphi / 2;                                                                          // :97
+        }
+        double psi = asinhD(tand((90.0 - phi) / 2) / a);      // generate_tripolar_coordinates.jl:66
+        double sh, ch;
+        sinh_cosh(psi, sh, ch);
+        int base = face ? 0 : 2;
+        t.tj[(base + 0) * t.Ny + (j - 1)] = sh;
+        t.tj[(base + 1) * t.Ny + (j - 1)] = ch;
+        return;
+    }
+    tid -= 2 * t.Ny;
+    if (tid <= t.Hy) {
+        // lat-lon continuation rows (src/tripolar_grid.jl:277-300); Oceananigans
+        // LatitudeLongitudeGrid metric formulas, SURVEY.md Appendix A-8
+        int j = 1 - t.Hy + tid;
+        const double south = t.south, R = t.R;
+        const double dlam = 360.0 / (double)t.Nx;
+        const double dphiL = (90.0 - south) / (double)t.Ny;
+        double pf, pfn, pc, pcm;
+        if (south == __builtin_rint(south)) {
+            long long s = (long long)south, Ny = t.Ny;
+            pf  = (double)(s * Ny + (90 - s) * (long long)(j - 1)) / (double)Ny;
+            pfn = (double)(s * Ny + (90 - s) * (long long)j) / (double)Ny;
+            pc  = (double)(2 * s * Ny + (90 - s) * (long long)(2 * j - 1)) / (double)(2 * Ny);
+            pcm = (double)(2 * s * Ny + (90 - s) * (long long)(2 * j - 3)) / (double)(2 * Ny);
+        } else {
+            pf  = south + (double)(j - 1) * dphiL;
+            pfn = south + (double)j * dphiL;
+            pc  = south + ((double)(2 * j - 1) * (90.0 - south)) / (double)(2 * t.Ny);
+            pcm = south + ((double)(2 * j - 3) * (90.0 - south)) / (double)(2 * t.Ny);
+        }
+        int n = t.Hy + 1;
+        t.ts[0 * n + tid] = R * (dlam * kDeg2Rad) * cosD(kPi * pc / 180);
+        t.ts[1 * n + tid] = R * (dlam * kDeg2Rad) * cosD(kPi * pf / 180);
+        t.ts[2 * n + tid] = R * R * (dlam * kDeg2Rad) * (sinD(kPi * pfn / 180) - sinD(kPi * pf / 180));
+        t.ts[3 * n + tid] = R * R * (dlam * kDeg2Rad) * (sinD(kPi * pc / 180) - sinD(kPi * pcm / 180));
+        t.ts[4 * n + tid] = R * (dphiL * kDeg2Rad);
+    }
+}
+
+// ---- the Murray (1996) map at one staggered point (generate_tripolar_coordinates.jl:66-87) ----
+struct LP { double lam, phi; };
+
+__device__ __forceinline__ LP analytic(const GridK& g, int xl, int yl, int is, int js)
+{
+    int i0 = is - g.shift; if (i0 < 1) i0 += g.Nx;           // pre-shift index drives the :75/:82 branches
+    const double* ti = g.ti + (xl == TPG_FACE ? 0 : 2) * g.Nx;
+    const double* tj = g.tj + (yl == TPG_FACE ? 0 : 2) * g.Ny;
+    double asl = ti[is - 1], acl = ti[g.Nx + is - 1];
+    double sh = tj[js - 1], ch = tj[g.Ny + js - 1];
+    double x = asl * ch;                                     // :67
+    double y = acl * sh;                                     // :68
+    bool pole = (x == 0.0) & (y == 0.0);                     // :74
+    double l = pole ? (i0 == 1 ? -90.0 : 90.0) : -kC180Pi * atanD(y / x);   // :75-77
+    LP r;
+    r.phi = 90.0 - kC360Pi * atanD(sqrt(y * y + x * x));     // :78
+    l += (i0 <= g.Nx / 2) ? -90.0 : 90.0;                    // :82
+    l += g.fplp90;                                           // :86
+    r.lam = fmod360(fmod360(l) + 360.0);                     // :87, OrthogonalSphericalShellGrids.jl:24
+    return r;
+}
+
+// x index of the fold partner (zipper_boundary_condition.jl:73-75, :90-92, :110, :125)
+__device__ __forceinline__ int fold_partner(int xl, int i, int Nx)
+{
+    int ip = (xl == TPG_FACE) ? Nx - i + 2 : Nx - i + 1;
+    return ip > Nx ? ip - Nx : ip;
+}
+
+// Value of the halo-filled coordinate field of location (xl,yl) at logical (i,j), i in 0..Nx+1,
+// j in 0..Ny+1: the composition of periodic x, north fold (sign +1, src/tripolar_grid.jl:147),
+// row-Ny substitution (zipper_boundary_condition.jl:102,135) and the zero south halo (:148).
+__device__ __forceinline__ LP coord(const GridK& g, int xl, int yl, int i, int j)
+{
+    if (j < 1) return LP{ 0.0, 0.0 };
+    int iw = i < 1 ? i + g.Nx : (i > g.Nx ? i - g.Nx : i);
+    int js = j;
+    if (j > g.Ny) {
+        int dj = j - g.Ny;
+        js = (yl == TPG_FACE) ? g.Ny - dj + 1 : g.Ny - dj;
+        iw = fold_partner(xl, iw, g.Nx);
+        if (js < 1) return LP{ 0.0, 0.0 };
+    } else if (j == g.Ny && yl == TPG_CENTER && iw > g.Nx / 2) {
+        iw = fold_partner(xl, iw, g.Nx);
+    }
+    return analytic(g, xl, yl, iw, js);
+}
+
+// Distances.haversine((l1,p1),(l2,p2),R), call sites src/tripolar_grid_utils.jl:13-21
+__device__ __forceinline__ double haversine(LP a, LP b, double R)
+{
+    double dl = (b.lam - a.lam) * kDeg2Rad;
+    double a1 = a.phi * kDeg2Rad;
+    double a2 = b.phi * kDeg2Rad;
+    double dp = a2 - a1;
+    double s1 = sinD(dp / 2), s2 = sinD(dl / 2);
+    double h = s1 * s1 + cosD(a1) * cosD(a2) * (s2 * s2);
+    double r = sqrt(h);
+    return 2 * (R * asinD(r != r ? r : (r < 1.0 ? r : 1.0)));
+}
+
+struct V3 { double x, y, z; };
+// Oceananigans lat_lon_to_cartesian(phi, lambda, 1)
+__device__ __forceinline__ V3 cartesian(LP p)
+{
+    double cl = cosd(p.phi);
+    return V3{ cosd(p.lam) * cl, sind(p.lam) * cl, sind(p.phi) };
+}
+__device__ __forceinline__ double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b)
+{
+    return V3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+}
+// Oceananigans spherical_area_triangle / spherical_area_quadrilateral
+__device__ __forceinline__ double tri_area(V3 a, V3 b, V3 c)
+{
+    double t = absD(dot3(a, cross3(b, c)));
+    t /= 1 + dot3(a, b) + dot3(b, c) + dot3(a, c);
+    return 2 * atanD(t);
+}
+__device__ __forceinline__ double quad_area(V3 a, V3 b, V3 c, V3 d)
+{
+    double A = tri_area(a, b, c);
+    A += tri_area(a, b, d);
+    A += tri_area(a, c, d);
+    A += tri_area(b, c, d);
+    return A / 2;
+}
+
+template <typename T>
+__device__ __forceinline__ void put(const OutPtrs& o, int q, long long off, double v)
+{
+    static_cast<T*>(o.p[q])[off] = (T)v;
+}
+
+// ---- K1: interior cells ------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_cells(GridK g, OutPtrs o)
+{
+    const int nbx = (g.Nx + 255) / 256;
+    int rb = blockIdx.x / nbx;
+    int i = (blockIdx.x - rb * nbx) * 256 + threadIdx.x + 1;
+    int j = g.jm_lo + rb;
+    if (i > g.Nx) return;
+
+    LP cc = coord(g, 0, 0, i, j), fc = coord(g, 1, 0, i, j), cf = coord(g, 0, 1, i, j), ff = coord(g, 1, 1, i, j);
+    LP fc_e = coord(g, 1, 0, i + 1, j), fc_s = coord(g, 1, 0, i, j - 1);
+    LP cc_w = coord(g, 0, 0, i - 1, j), cc_s = coord(g, 0, 0, i, j - 1), cc_sw = coord(g, 0, 0, i - 1, j - 1);
+    LP ff_e = coord(g, 1, 1, i + 1, j), ff_n = coord(g, 1, 1, i, j + 1), ff_ne = coord(g, 1, 1, i + 1, j + 1);
+    LP cf_w = coord(g, 0, 1, i - 1, j), cf_n = coord(g, 0, 1, i, j + 1);
+
+    const double R = g.R;
+    double dxcc = haversine(fc_e, fc, R);      // tripolar_grid_utils.jl:13
+    double dxfc = haversine(cc, cc_w, R);      // :14
+    double dxcf = haversine(ff_e, ff, R);      // :15
+    double dxff = haversine(cf, cf_w, R);      // :16
+    double dycc = haversine(cf_n, cf, R);      // :18
+    double dyfc = haversine(ff_n, ff, R);      // :19
+    double dycf = haversine(cc, cc_s, R);      // :20
+    double dyff = haversine(fc, fc_s, R);      // :21
+    double azcc = quad_area(cartesian(ff), cartesian(ff_e), cartesian(ff_ne), cartesian(ff_n)) * (R * R);   // :23-28
+    double azfc = dyfc * dxfc;                 // :34
+    double azcf = dycf * dxcf;                 // :35
+    double azff = quad_area(cartesian(cc_sw), cartesian(cc_s), cartesian(cc), cartesian(cc_w)) * (R * R);   // :38-43
+
+    long long off = (long long)(i + g.Hx - 1) + (long long)g.sx * (j - g.jstart + g.Hy);
+    put<T>(o, TPG_LAMBDA_CC, off, cc.lam); put<T>(o, TPG_LAMBDA_FC, off, fc.lam);
+    put<T>(o, TPG_LAMBDA_CF, off, cf.lam); put<T>(o, TPG_LAMBDA_FF, off, ff.lam);
+    put<T>(o, TPG_PHI_CC, off, cc.phi); put<T>(o, TPG_PHI_FC, off, fc.phi);
+    put<T>(o, TPG_PHI_CF, off, cf.phi); put<T>(o, TPG_PHI_FF, off, ff.phi);
+    put<T>(o, TPG_DX_CC, off, dxcc); put<T>(o, TPG_DX_FC, off, dxfc);
+    put<T>(o, TPG_DX_CF, off, dxcf); put<T>(o, TPG_DX_FF, off, dxff);
+    put<T>(o, TPG_DY_CC, off, dycc); put<T>(o, TPG_DY_CF, off, dycf);
+    put<T>(o, TPG_DY_FC, off, dyfc); put<T>(o, TPG_DY_FF, off, dyff);
+    put<T>(o, TPG_AZ_CC, off, azcc); put<T>(o, TPG_AZ_FC, off, azfc);
+    put<T>(o, TPG_AZ_CF, off, azcf); put<T>(o, TPG_AZ_FF, off, azff);
+}
+
+// ---- K2: halo cells of the 20 arrays ------------------------------------------------------------
+// x/y location of array q (order of enum tpg_array)
+__device__ __forceinline__ void array_loc(int q, int& xl, int& yl)
+{
+    // cc, fc, cf, ff for every group except dy (cc, cf, fc, ff)
+    int r = q & 3;
+    bool dy = (q >= TPG_DY_CC && q <= TPG_DY_FF);
+    int xr = dy ? (r >> 1) : (r & 1);
+    int yr = dy ? (r & 1) : (r >> 1);
+    xl = xr; yl = yr;
+}
+
+struct HaloRegions {
+    int nA;   // x-halo columns of evaluated rows: (jm_hi-jm_lo+1) * 2Hx
+    int nB;   // north rows j = Ny+1..Ny+Hy (north rank): Hy * sx
+    int nC;   // south rows j < 1 present in the band: nsouth * sx
+    int nD;   // row-Ny substitution cells i = Nx/2+1..Nx (north rank): Nx/2
+    int nsouth;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_halos(GridK g, OutPtrs o, HaloRegions h)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int q = blockIdx.y;
+    int xl, yl;
+    array_loc(q, xl, yl);
+    const bool is_coord = q < TPG_DX_CC;
+    T* A = static_cast<T*>(o.p[q]);
+    const long long sx = g.sx;
+    auto at = [&](int i, int j) -> long long { return (long long)(i + g.Hx - 1) + sx * (j - g.jstart + g.Hy); };
+
+    int i, j;
+    if (t < h.nA) {
+        int r = t / (2 * g.Hx), c = t - r * 2 * g.Hx;
+        j = g.jm_lo + r;
+        i = c < g.Hx ? 1 - g.Hx + c : g.Nx + 1 + (c - g.Hx);
+    } else if ((t -= h.nA) < h.nB) {
+        int r = t / g.sx, c = t - r * g.sx;
+        j = g.Ny + 1 + r; i = 1 - g.Hx + c;
+    } else if ((t -= h.nB) < h.nC) {
+        int r = t / g.sx, c = t - r * g.sx;
+        j = 1 - h.nsouth + r; i = 1 - g.Hx + c;
+        if (is_coord) A[at(i, j)] = (T)0;        // south = nothing: halos stay zero (tripolar_grid.jl:148)
+        return;                                  // metrics: rows j <= 1 belong to K3
+    } else if ((t -= h.nC) < h.nD) {
+        if (is_coord || yl != TPG_CENTER) return; // coordinates were evaluated through the substitution already
+        i = g.Nx / 2 + 1 + t; j = g.Ny;
+    } else {
+        return;
+    }
+
+    int iw = i < 1 ? i + g.Nx : (i > g.Nx ? i - g.Nx : i);
+    int js = j;
+    if (j > g.Ny) {
+        int dj = j - g.Ny;
+        js = (yl == TPG_FACE) ? g.Ny - dj + 1 : g.Ny - dj;
+        iw = fold_partner(xl, iw, g.Nx);
+        if (js < 1) { A[at(i, j)] = (T)0; return; }     // folds a zero south-halo row (Ny <= Hy grids)
+    } else if (j == g.Ny && yl == TPG_CENTER && iw > g.Nx / 2) {
+        iw = fold_partner(xl, iw, g.Nx);
+    }
+    A[at(i, j)] = A[at(iw, js)];
+}
+
+// ---- K3: lat-lon continuation rows (continue_south!, src/tripolar_grid.jl:287-300,336-357) ----
+template <typename T>
+__global__ __launch_bounds__(256) void k_south(GridK g, OutPtrs o)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y;                              // global row j = 1-Hy+r
+    int lr = (1 - g.Hy + r) - (g.jstart - g.Hy);     // local row of the band
+    if (c >= g.sx || lr < 0 || lr >= g.rows) return;
+    int n = g.Hy + 1;
+    double dxc = g.ts[0 * n + r], dxf = g.ts[1 * n + r], azc = g.ts[2 * n + r], azf = g.ts[3 * n + r], dy = g.ts[4 * n + r];
+    long long off = (long long)c + (long long)g.sx * lr;
+    put<T>(o, TPG_DX_FF, off, dxf); put<T>(o, TPG_DX_FC, off, dxc); put<T>(o, TPG_DX_CF, off, dxf); put<T>(o, TPG_DX_CC, off, dxc);
+    put<T>(o, TPG_DY_FF, off, dy);  put<T>(o, TPG_DY_FC, off, dy);  put<T>(o, TPG_DY_CF, off, dy);  put<T>(o, TPG_DY_CC, off, dy);
+    put<T>(o, TPG_AZ_FF, off, azf); put<T>(o, TPG_AZ_FC, off, azc); put<T>(o, TPG_AZ_CF, off, azf); put<T>(o, TPG_AZ_CC, off, azc);
+}
+
+size_t table_doubles(const tpg_params* p) { return 4 * (size_t)p->Nx + 4 * (size_t)p->Ny + 5 * (size_t)(p->Hy + 1); }
+
+int check_params(const tpg_params* p)
+{
+    if (!p) { tpg::set_error("null params"); return TPG_ERR_INVALID_ARGUMENT; }
+    int rc = tpg::check_geom(p->Nx, p->Ny, p->Nz, p->Hx, p->Hy, p->Hz, p->ft);
+    if (rc) return rc;
+    if (p->jstart < 1 || p->jend > p->Ny || p->jend < p->jstart) {
+        tpg::set_error("latitude band %d:%d outside 1:%d", p->jstart, p->jend, p->Ny);
+        return TPG_ERR_BAD_PARTITION;
+    }
+    if (!(p->radius > 0) || !(p->north_poles_latitude < 90) || !(p->southernmost_latitude < 90)) {
+        tpg::set_error("invalid radius / latitudes");
+        return TPG_ERR_INVALID_ARGUMENT;
+    }
+    return TPG_OK;
+}
+
+template <typename T>
+int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStream_t s)
+{
+    dim3 grid1(((g.Nx + 255) / 256) * (g.jm_hi - g.jm_lo + 1));
+    hipLaunchKernelGGL(k_cells<T>, grid1, dim3(256), 0, s, g, o);
+    int rc = tpg::launch_status("k_cells");
+    if (rc) return rc;
+    int nh = h.nA + h.nB + h.nC + h.nD;
+    if (nh > 0) {
+        hipLaunchKernelGGL(k_halos<T>, dim3((nh + 255) / 256, TPG_NUM_ARRAYS), dim3(256), 0, s, g, o, h);
+        if ((rc = tpg::launch_status("k_halos"))) return rc;
+    }
+    if (g.jstart - g.Hy <= 1) {
+        hipLaunchKernelGGL(k_south<T>, dim3((g.sx + 255) / 256, g.Hy + 1), dim3(256), 0, s, g, o);
+        if ((rc = tpg::launch_status("k_south"))) return rc;
+    }
+    return TPG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tpg_build_grid_workspace_bytes(const tpg_params* p)
+{
+    if (!p || p->Nx < 1 || p->Ny < 1 || p->Hy < 0) return 0;
+    return (table_doubles(p) * sizeof(double) + 255) & ~(size_t)255;
+}
+
+int tpg_build_grid(const tpg_params* p, void* const out[TPG_NUM_ARRAYS], void* workspace,
+                   size_t workspace_bytes, void* stream)
+{
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!out) { tpg::set_error("null output table"); return TPG_ERR_INVALID_ARGUMENT; }
+    OutPtrs o;
+    for (int q = 0; q < TPG_NUM_ARRAYS; ++q) {
+        if (!out[q]) { tpg::set_error("null output array %d", q); return TPG_ERR_INVALID_ARGUMENT; }
+        o.p[q] = out[q];
+    }
+    if (!workspace || workspace_bytes < table_doubles(p) * sizeof(double) || ((uintptr_t)workspace & 7)) {
+        tpg::set_error("workspace: need %zu bytes, 8-byte aligned", table_doubles(p) * sizeof(double));
+        return TPG_ERR_WORKSPACE;
+    }
+    hipStream_t s = tpg::as_stream(stream);
+    double* w = static_cast<double*>(workspace);
+
+    TableArgs t;
+    t.Nx = p->Nx; t.Ny = p->Ny; t.Hy = p->Hy; t.shift = p->Nx / 4; t.ft = p->ft;
+    t.south = p->southernmost_latitude; t.npl = p->north_poles_latitude; t.R = p->radius;
+    t.ti = w; t.tj = w + 4 * (size_t)p->Nx; t.ts = t.tj + 4 * (size_t)p->Ny;
+    int nt = p->Nx + 2 * p->Ny + p->Hy + 1;
+    hipLaunchKernelGGL(k_tables, dim3((nt + 63) / 64), dim3(64), 0, s, t);
+    if ((rc = tpg::launch_status("k_tables"))) return rc;
+
+    GridK g;
+    g.Nx = p->Nx; g.Ny = p->Ny; g.Hx = p->Hx; g.Hy = p->Hy; g.shift = p->Nx / 4;
+    g.jstart = p->jstart; g.jend = p->jend;
+    g.jm_lo = p->jstart - p->Hy < 1 ? 1 : p->jstart - p->Hy;
+    g.jm_hi = p->jend + p->Hy > p->Ny ? p->Ny : p->jend + p->Hy;
+    g.sx = p->Nx + 2 * p->Hx; g.rows = p->jend - p->jstart + 1 + 2 * p->Hy;
+    g.ft = p->ft; g.fplp90 = p->first_pole_longitude + 90.0; g.R = p->radius;
+    g.ti = t.ti; g.tj = t.tj; g.ts = t.ts;
+
+    HaloRegions h;
+    h.nA = (g.jm_hi - g.jm_lo + 1) * 2 * g.Hx;
+    h.nB = (p->jend == p->Ny) ? g.Hy * g.sx : 0;
+    h.nsouth = (1 - (p->jstart - p->Hy)) > 0 ? (1 - (p->jstart - p->Hy)) : 0;   // rows j < 1 in the band
+    h.nC = h.nsouth * g.sx;
+    h.nD = (p->jend == p->Ny) ? p->Nx / 2 : 0;
+
+    if (p->ft == TPG_F64) return launch_build<double>(g, o, h, s);
+    return launch_build<float>(g, o, h, s);
+}
+
+}  // extern "C"

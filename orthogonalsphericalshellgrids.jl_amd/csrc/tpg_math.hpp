@@ -1,0 +1,346 @@
+// tpg_math.hpp -- deterministic Float64 elementary functions for gfx950 device code.
+//
+// The TripolarGrid metric precompute must agree with the CPU reference path to <= 1e-12
+// relative on Float64 metrics (BASELINE.json north_star).  Edge lengths are haversines of
+// *differences* of O(100 deg) coordinates, so a 1-ulp coordinate discrepancy already costs
+// ~5e-13 at 1/10 deg ("Conditioning").  OCML's sin/cos/atan/asin are not
+// bit-compatible with any host libm, therefore every transcendental used on the path is built
+// here from IEEE-754 correctly rounded primitives only (+ - * / sqrt fma rint, bit ops): the same
+// operation sequence gives the same bits on any IEEE machine.  Must be compiled with
+// -ffp-contract=off (fusions are explicit __builtin_fma).
+//
+// Algorithms: FreeBSD msun family (k_sin, k_cos, e_rem_pio2 medium path, s_atan, e_asin) -- the
+// algorithms Julia Base ports for sin/cos/atan/asin -- plus Julia-style degree-exact sind/cosd
+// (exact rem(x,360) reduction, octant selection, double-double deg->rad product), and a
+// double-double exp/log for the O(Ny) latitude-stretching table (asinh, sinh, cosh).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tpgm {
+
+#define TPG_DEV __device__ __forceinline__
+
+constexpr double kPi       = 0x1.921fb54442d18p+1;
+constexpr double kDeg2Rad  = 0x1.1df46a2529d39p-6;    // Float64(pi)/180  (Julia deg2rad)
+constexpr double kDeg2RadLo = 0x1.5c1d8becdd291p-62;  // pi/180 - kDeg2Rad
+constexpr double kInvPio2  = 0x1.45f306dc9c883p-1;
+constexpr double kPio2_1   = 0x1.921fb54400000p+0;
+constexpr double kPio2_1t  = 0x1.0b4611a626331p-34;
+constexpr double kPio2_2   = 0x1.0b4611a600000p-34;
+constexpr double kPio2_2t  = 0x1.3198a2e037073p-69;
+constexpr double kPio2_3   = 0x1.3198a2e000000p-69;
+constexpr double kPio2_3t  = 0x1.b839a252049c1p-104;
+constexpr double kPio2Hi   = 0x1.921fb54442d18p+0;
+constexpr double kPio2Lo   = 0x1.1a62633145c07p-54;
+constexpr double kPio4Hi   = 0x1.921fb54442d18p-1;
+constexpr double kLn2Hi    = 0x1.62e42fefa39efp-1;
+constexpr double kLn2Lo    = 0x1.abc9e3b39803fp-56;
+
+TPG_DEV uint64_t bits(double x) { return (uint64_t)__double_as_longlong(x); }
+TPG_DEV double from_bits(uint64_t u) { return __longlong_as_double((long long)u); }
+TPG_DEV int expo(double x) { return (int)((bits(x) >> 52) & 0x7ff); }
+TPG_DEV double fmaD(double a, double b, double c) { return __builtin_fma(a, b, c); }
+TPG_DEV double absD(double x) { return __builtin_fabs(x); }
+TPG_DEV double csign(double mag, double sgn) { return __builtin_copysign(mag, sgn); }
+
+// exact fmod(x, 360): identity / one exact subtraction (Sterbenz) on the ranges the grid uses,
+// generic exact remainder otherwise.
+TPG_DEV double fmod360(double x)
+{
+    double ax = absD(x);
+    if (ax < 360.0) return x;
+    if (ax < 720.0) return csign(ax - 360.0, x);
+    return fmod(x, 360.0);
+}
+
+// ---- kernels on [-pi/4, pi/4], argument x + y (double-double)
+TPG_DEV double ksin(double x, double y)
+{
+    double z = x * x;
+    double r = fmaD(z, fmaD(z, fmaD(z, fmaD(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                    2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                    8.33333333332248946124e-03);
+    double v = z * x;
+    return x - ((z * (0.5 * y - v * r) - y) - v * -1.66666666666666324348e-01);
+}
+TPG_DEV double kcos(double x, double y)
+{
+    double z = x * x;
+    double r = z * fmaD(z, fmaD(z, fmaD(z, fmaD(z, fmaD(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                            -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    double hz = 0.5 * z;
+    double w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+
+// ---- Cody-Waite reduction by pi/2 (|x| < 2^20 pi/2)
+TPG_DEV int rem_pio2(double x, double& y0, double& y1)
+{
+    double fn = __builtin_rint(x * kInvPio2);
+    int n = (int)fn;
+    double r = x - fn * kPio2_1;
+    double w = fn * kPio2_1t;
+    int j = expo(x);
+    double a = r - w;
+    if (j - expo(a) > 16) {
+        double t = r;
+        w = fn * kPio2_2;
+        r = t - w;
+        w = fn * kPio2_2t - ((t - r) - w);
+        a = r - w;
+        if (j - expo(a) > 49) {
+            t = r;
+            w = fn * kPio2_3;
+            r = t - w;
+            w = fn * kPio2_3t - ((t - r) - w);
+            a = r - w;
+        }
+    }
+    y0 = a;
+    y1 = (r - a) - w;
+    return n;
+}
+
+// sin and cos of the same radian argument (haversine needs both kinds on different arguments;
+// sharing the reduction is free determinism-wise: each output equals the scalar function)
+TPG_DEV double sinD(double x)
+{
+    if (!(absD(x) <= kPio4Hi)) {
+        double y0, y1;
+        int n = rem_pio2(x, y0, y1);
+        double s = ksin(y0, y1), c = kcos(y0, y1);
+        double v = (n & 1) ? c : s;
+        return (n & 2) ? -v : v;
+    }
+    if (expo(x) < 0x3e5) return x;
+    return ksin(x, 0.0);
+}
+TPG_DEV double cosD(double x)
+{
+    if (!(absD(x) <= kPio4Hi)) {
+        double y0, y1;
+        int n = rem_pio2(x, y0, y1);
+        double s = ksin(y0, y1), c = kcos(y0, y1);
+        double v = (n & 1) ? s : c;
+        return ((n + 1) & 2) ? -v : v;
+    }
+    return kcos(x, 0.0);
+}
+
+// ---- degree trig
+TPG_DEV void deg2rad_ext(double x, double& hi, double& lo)
+{
+    double h = x * kDeg2Rad;
+    lo = fmaD(x, kDeg2Rad, -h) + x * kDeg2RadLo;
+    hi = h;
+}
+TPG_DEV double sind(double x)
+{
+    double rx = csign(fmod360(x), x);
+    double arx = absD(rx);
+    if (rx == 0.0) return rx;
+    if (arx == 180.0) return csign(0.0, rx);
+    double arg, sg;
+    bool use_cos, neg = false;
+    if (arx < 45.0)        { arg = rx; use_cos = false; sg = 0.0; }
+    else if (arx <= 135.0) { arg = 90.0 - arx; use_cos = true; sg = rx; }
+    else if (arx < 225.0)  { arg = (180.0 - arx) * csign(1.0, rx); use_cos = false; sg = 0.0; }
+    else if (arx <= 315.0) { arg = 270.0 - arx; use_cos = true; sg = rx; neg = true; }
+    else                   { arg = rx - csign(360.0, rx); use_cos = false; sg = 0.0; }
+    double h, l;
+    deg2rad_ext(arg, h, l);
+    if (use_cos) {
+        double c = csign(kcos(h, l), sg);
+        return neg ? -c : c;
+    }
+    return ksin(h, l);
+}
+TPG_DEV double cosd(double x)
+{
+    double rx = absD(fmod360(x));
+    double arg;
+    bool use_sin, neg = false;
+    if (rx <= 45.0)       { arg = rx; use_sin = false; }
+    else if (rx < 135.0)  { arg = 90.0 - rx; use_sin = true; }
+    else if (rx <= 225.0) { arg = 180.0 - rx; use_sin = false; neg = true; }
+    else if (rx < 315.0)  { arg = rx - 270.0; use_sin = true; }
+    else                  { arg = 360.0 - rx; use_sin = false; }
+    double h, l;
+    deg2rad_ext(arg, h, l);
+    if (use_sin) return ksin(h, l);
+    double c = kcos(h, l);
+    return neg ? -c : c;
+}
+TPG_DEV double tand(double x) { return sind(x) / cosd(x); }
+
+// ---- atan
+TPG_DEV double atanD(double x)
+{
+    double ax = absD(x);
+    if (x != x) return x;
+    if (ax >= 0x1p66) return csign(kPio2Hi + kPio2Lo, x);
+    if (ax < 0x1p-27) return x;
+    double num, den, hi, lo;
+    bool direct = ax < 0.4375;
+    if (ax < 0.6875)      { num = 2.0 * ax - 1.0; den = 2.0 + ax;       hi = 0x1.dac670561bb4fp-2; lo = 0x1.a2b7f222f65e2p-56; }
+    else if (ax < 1.1875) { num = ax - 1.0;       den = ax + 1.0;       hi = 0x1.921fb54442d18p-1; lo = 0x1.1a62633145c07p-55; }
+    else if (ax < 2.4375) { num = ax - 1.5;       den = 1.0 + 1.5 * ax; hi = 0x1.f730bd281f69bp-1; lo = 0x1.007887af0cbbdp-56; }
+    else                  { num = -1.0;           den = ax;             hi = kPio2Hi;              lo = kPio2Lo; }
+    double t = direct ? ax : num / den;
+    double z = t * t;
+    double w = z * z;
+    double s1 = z * fmaD(w, fmaD(w, fmaD(w, fmaD(w, fmaD(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02),
+                                              6.66107313738753120669e-02), 9.09088713343650656196e-02),
+                                  1.42857142725034663711e-01), 3.33333333333329318027e-01);
+    double s2 = w * fmaD(w, fmaD(w, fmaD(w, fmaD(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02),
+                                      -7.69187620504482999495e-02), -1.11111104054623557880e-01),
+                          -1.99999999998764832476e-01);
+    double r = direct ? t - t * (s1 + s2) : hi - ((t * (s1 + s2) - lo) - t);
+    return csign(r, x);
+}
+
+// ---- asin
+TPG_DEV double asin_pq(double t)
+{
+    double p = t * fmaD(t, fmaD(t, fmaD(t, fmaD(t, fmaD(t, 3.47933107596021167570e-05, 7.91534994289814532176e-04),
+                                            -4.00555345006794114027e-02), 2.01212532134862925881e-01),
+                                -3.25565818622400915405e-01), 1.66666666666666657415e-01);
+    double q = fmaD(t, fmaD(t, fmaD(t, fmaD(t, 7.70381505559019352791e-02, -6.88283971605453293030e-01),
+                                    2.02094576023350569471e+00), -2.40339491173441421878e+00), 1.0);
+    return p / q;
+}
+TPG_DEV double asinD(double x)
+{
+    double ax = absD(x);
+    if (ax >= 1.0) {
+        if (ax == 1.0) return x * kPio2Hi + x * kPio2Lo;
+        return (x - x) / (x - x);
+    }
+    if (ax < 0.5) {
+        if (ax < 0x1p-26) return x;
+        return x + x * asin_pq(x * x);
+    }
+    double w = 1.0 - ax;
+    double t = w * 0.5;
+    double r = asin_pq(t);
+    double s = sqrt(t);
+    double res;
+    if (ax >= 0.975) {
+        res = kPio2Hi - (2.0 * (s + s * r) - kPio2Lo);
+    } else {
+        double f = from_bits(bits(s) & 0xffffffff00000000ull);
+        double c = (t - f * f) / (s + f);
+        double p = 2.0 * s * r - (kPio2Lo - 2.0 * c);
+        double q = kPio4Hi - 2.0 * f;
+        res = kPio4Hi - (p - q);
+    }
+    return csign(res, x);
+}
+
+// ---- double-double toolkit (latitude-stretching table only)
+struct dd { double hi, lo; };
+TPG_DEV dd two_sum(double a, double b) { double s = a + b, bb = s - a; return { s, (a - (s - bb)) + (b - bb) }; }
+TPG_DEV dd quick_two_sum(double a, double b) { double s = a + b; return { s, b - (s - a) }; }
+TPG_DEV dd two_prod(double a, double b) { double p = a * b; return { p, fmaD(a, b, -p) }; }
+TPG_DEV dd dd_add(dd a, dd b)
+{
+    dd s = two_sum(a.hi, b.hi), t = two_sum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = quick_two_sum(s.hi, s.lo);
+    s.lo += t.lo;
+    return quick_two_sum(s.hi, s.lo);
+}
+TPG_DEV dd dd_neg(dd a) { return { -a.hi, -a.lo }; }
+TPG_DEV dd dd_sub(dd a, dd b) { return dd_add(a, dd_neg(b)); }
+TPG_DEV dd dd_mul(dd a, dd b)
+{
+    dd p = two_prod(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return quick_two_sum(p.hi, p.lo);
+}
+TPG_DEV dd dd_mul_d(dd a, double b)
+{
+    dd p = two_prod(a.hi, b);
+    p.lo += a.lo * b;
+    return quick_two_sum(p.hi, p.lo);
+}
+TPG_DEV dd dd_div(dd a, dd b)
+{
+    double q1 = a.hi / b.hi;
+    dd r = dd_sub(a, dd_mul_d(b, q1));
+    double q2 = r.hi / b.hi;
+    r = dd_sub(r, dd_mul_d(b, q2));
+    double q3 = r.hi / b.hi;
+    dd q = quick_two_sum(q1, q2);
+    return dd_add(q, dd{ q3, 0.0 });
+}
+TPG_DEV dd dd_sqrt(dd a)
+{
+    if (a.hi <= 0.0) return { 0.0, 0.0 };
+    double x = 1.0 / sqrt(a.hi);
+    double ax = a.hi * x;
+    dd e = dd_sub(a, two_prod(ax, ax));
+    return two_sum(ax, e.hi * (x * 0.5));
+}
+__device__ __noinline__ dd dd_expm1_reduced(dd a, int& kout)
+{
+    const dd ln2 = { kLn2Hi, kLn2Lo };
+    double kf = __builtin_rint(a.hi / kLn2Hi);
+    dd r = dd_sub(a, dd_mul_d(ln2, kf));
+    r.hi *= 0x1p-9; r.lo *= 0x1p-9;
+    dd term = r, s = r;
+    for (int n = 2; n <= 11; ++n) {
+        term = dd_mul(term, r);
+        term = dd_div(term, dd{ (double)n, 0.0 });
+        s = dd_add(s, term);
+    }
+    for (int i = 0; i < 9; ++i) s = dd_add(dd_mul_d(s, 2.0), dd_mul(s, s));
+    kout = (int)kf;
+    return s;
+}
+TPG_DEV dd dd_exp(dd a)
+{
+    int k;
+    dd s = dd_expm1_reduced(a, k);
+    dd e = dd_add(dd{ 1.0, 0.0 }, s);
+    double sc = from_bits((uint64_t)(1023 + k) << 52);
+    e.hi *= sc; e.lo *= sc;
+    return e;
+}
+TPG_DEV dd dd_log(dd a)
+{
+    int e = expo(a.hi) - 1023;
+    double m = from_bits((bits(a.hi) & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    if (m > 0x1.6a09e667f3bcdp+0) { m *= 0.5; e += 1; }
+    double u = (m - 1.0) / (m + 1.0), u2 = u * u;
+    double ser = u * (2.0 + u2 * (2.0 / 3.0 + u2 * (2.0 / 5.0 + u2 * (2.0 / 7.0 + u2 * (2.0 / 9.0
+                 + u2 * (2.0 / 11.0 + u2 * (2.0 / 13.0)))))));
+    dd y = two_sum((double)e * kLn2Hi, ser);
+    for (int it = 0; it < 3; ++it) {
+        dd ey = dd_exp(dd_neg(y));
+        dd c = dd_sub(dd_mul(a, ey), dd{ 1.0, 0.0 });
+        y = dd_add(y, c);
+    }
+    return y;
+}
+TPG_DEV double asinhD(double x)
+{
+    double ax = absD(x);
+    if (ax == 0.0 || x != x) return x;
+    dd s = dd_sqrt(dd_add(two_prod(ax, ax), dd{ 1.0, 0.0 }));
+    dd l = dd_log(dd_add(dd{ ax, 0.0 }, s));
+    return csign(l.hi + l.lo, x);
+}
+TPG_DEV void sinh_cosh(double x, double& sh, double& ch)
+{
+    double ax = absD(x);
+    dd e = dd_exp(dd{ ax, 0.0 });
+    dd ie = dd_div(dd{ 1.0, 0.0 }, e);
+    dd s = dd_sub(e, ie), c = dd_add(e, ie);
+    sh = csign(0.5 * (s.hi + s.lo), x);
+    ch = 0.5 * (c.hi + c.lo);
+}
+
+}  // namespace tpgm

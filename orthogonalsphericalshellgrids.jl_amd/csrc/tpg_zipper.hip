@@ -1,0 +1,392 @@
+// tpg_zipper.hip -- north-seam Zipper halo fill (index reversal + vector sign flip) for gfx950,
+// plus the periodic-x pass and the latitude-band pack/unpack kernels that sit either side of it.
+//
+// Replaces fold_north_{center_center,face_center,center_face,face_face}!
+// (src/zipper_boundary_condition.jl:70-138) as invoked per (i,k) by _fill_north_halo! (:146-155).
+//
+// HBM-bound integer/index work, no MFMA.  Design:
+//  * one launch folds a whole BATCH of fields (pointer table in the kernarg segment), all levels;
+//  * a work item is one 16-byte chunk (2 doubles / 4 floats) of one destination row: rows
+//    Ny+1..Ny+Hy, plus the upper half of row Ny for y-Center fields (the row-Ny substitution);
+//  * consecutive lanes own consecutive destination chunks (ascending, 16-B aligned stores) and
+//    read the mirrored source chunk (descending addresses, one contiguous 1 KiB window per wave),
+//    reverse it in registers and multiply by the sign;
+//  * x-Face rows mirror about an odd offset (i' = Nx - i + 2): their source windows are 8-B (f64)
+//    / 4-B (f32) off 16-B alignment, read with dword-aligned wide loads;
+//  * a 1-D grid of 256-thread blocks, grid-stride free (one item per thread), 64-bit element
+//    offsets, 32-bit item indices.
+// Geometries whose rows are not 16-B chunkable (odd Hx for f64, Hx or Nx not multiple of 4 for
+// f32, misaligned base pointers) run the scalar kernel (one element per item).
+#include "tpg_common.hpp"
+
+namespace {
+
+using tpg::Geom;
+
+struct FieldTable {
+    void* ptr[TPG_MAX_FIELDS];
+    int item0[TPG_MAX_FIELDS + 1];   // prefix sums of work items per field
+    int8_t xloc[TPG_MAX_FIELDS];
+    int8_t yloc[TPG_MAX_FIELDS];
+    int sign[TPG_MAX_FIELDS];
+    int nfields;
+};
+
+struct ZipArgs {
+    int Nx, Ny, Hx, Hy, Hz;
+    int sx;
+    long long plane;
+    int kstart, kcount;
+    int nchunks;     // chunks per destination row (vector kernel) or Nx (scalar kernel)
+    int fix0;        // first chunk (vector) / element (scalar, 0-based) of the row-Ny substitution
+};
+
+template <typename T, int W> struct Vec;
+template <> struct Vec<double, 2> {
+    typedef double aligned_t __attribute__((ext_vector_type(2)));
+    typedef double loose_t __attribute__((ext_vector_type(2), aligned(8)));
+};
+template <> struct Vec<float, 4> {
+    typedef float aligned_t __attribute__((ext_vector_type(4)));
+    typedef float loose_t __attribute__((ext_vector_type(4), aligned(4)));
+};
+
+__device__ __forceinline__ int find_field(const FieldTable& ft, int item)
+{
+    int f = 0;
+#pragma unroll 1
+    while (f + 1 < ft.nfields && item >= ft.item0[f + 1]) ++f;
+    return f;
+}
+
+// ---- vector kernel: W elements (16 B) per work item ----------------------------------------
+template <typename T, int W>
+__global__ __launch_bounds__(256) void k_zipper_vec(FieldTable ft, ZipArgs a)
+{
+    typedef typename Vec<T, W>::aligned_t vec_t;
+    typedef typename Vec<T, W>::loose_t lvec_t;
+    int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= ft.item0[ft.nfields]) return;
+    const int f = find_field(ft, item);
+    item -= ft.item0[f];
+    const int xl = ft.xloc[f], yl = ft.yloc[f];
+    const int sgn = ft.sign[f];
+    T* __restrict__ c = static_cast<T*>(ft.ptr[f]);
+
+    // items of one level: Hy full rows, then (y-Center only) the upper part of row Ny
+    const int nfix = (yl == TPG_CENTER) ? a.nchunks - a.fix0 : 0;
+    const int per_level = a.Hy * a.nchunks + nfix;
+    const int kk = item / per_level;
+    int r = item - kk * per_level;
+    int jrow, ch;            // destination row slot: 1..Hy halo rows, 0 = row Ny
+    if (r < a.Hy * a.nchunks) { jrow = r / a.nchunks + 1; ch = r - (jrow - 1) * a.nchunks; }
+    else { jrow = 0; ch = a.fix0 + (r - a.Hy * a.nchunks); }
+
+    const int k = a.kstart + kk;                                   // 1-based level
+    const int jdst = a.Ny + jrow;
+    // source row: y-Face  Ny - j + 1, y-Center  Ny - j  (row fix: Ny)        (:80,:97,:115,:130)
+    const int jsrc = (jrow == 0) ? a.Ny : ((yl == TPG_FACE) ? a.Ny - jrow + 1 : a.Ny - jrow);
+    const long long kbase = a.plane * (k + a.Hz - 1);
+    T* dst = c + kbase + (long long)a.sx * (jdst + a.Hy - 1) + a.Hx;     // -> element i = 1
+    const T* src = c + kbase + (long long)a.sx * (jsrc + a.Hy - 1) + a.Hx;
+
+    const int i = ch * W + 1;                                      // first destination index
+    T out[W];
+    if (xl == TPG_CENTER) {
+        // i' = Nx - i + 1: destination i..i+W-1 <- source Nx-i+1 .. Nx-i-W+2 (descending)
+        const vec_t v = *reinterpret_cast<const vec_t*>(src + (a.Nx - i - W + 1));
+#pragma unroll
+        for (int e = 0; e < W; ++e) out[e] = (T)sgn * v[W - 1 - e];
+    } else {
+        // i' = Nx - i + 2, wrapping to 1 with |sign| at i = 1           (:73-75, :90-92)
+        if (ch == 0) {
+            out[0] = (T)(sgn < 0 ? -sgn : sgn) * src[0];
+#pragma unroll
+            for (int e = 1; e < W; ++e) out[e] = (T)sgn * src[a.Nx - e];
+        } else {
+            const lvec_t v = *reinterpret_cast<const lvec_t*>(src + (a.Nx - i - W + 2));
+#pragma unroll
+            for (int e = 0; e < W; ++e) out[e] = (T)sgn * v[W - 1 - e];
+        }
+    }
+    if (jrow == 0) {
+        // c[i,Ny] = ifelse(i > Nx/2, sign*c[i',Ny], c[i,Ny])            (:102, :135)
+        const vec_t old = *reinterpret_cast<const vec_t*>(dst + (i - 1));
+#pragma unroll
+        for (int e = 0; e < W; ++e) if (i + e <= a.Nx / 2) out[e] = old[e];
+    }
+    vec_t o;
+#pragma unroll
+    for (int e = 0; e < W; ++e) o[e] = out[e];
+    *reinterpret_cast<vec_t*>(dst + (i - 1)) = o;
+}
+
+// ---- scalar kernel: any geometry / alignment ---------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_zipper_scalar(FieldTable ft, ZipArgs a)
+{
+    int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= ft.item0[ft.nfields]) return;
+    const int f = find_field(ft, item);
+    item -= ft.item0[f];
+    const int xl = ft.xloc[f], yl = ft.yloc[f];
+    int sgn = ft.sign[f];
+    T* c = static_cast<T*>(ft.ptr[f]);
+    const int nfix = (yl == TPG_CENTER) ? a.Nx - a.fix0 : 0;
+    const int per_level = a.Hy * a.Nx + nfix;
+    const int kk = item / per_level;
+    int r = item - kk * per_level;
+    int jrow, i;
+    if (r < a.Hy * a.Nx) { jrow = r / a.Nx + 1; i = r - (jrow - 1) * a.Nx + 1; }
+    else { jrow = 0; i = a.fix0 + (r - a.Hy * a.Nx) + 1; }
+    const int k = a.kstart + kk;
+    int ip = (xl == TPG_FACE) ? a.Nx - i + 2 : a.Nx - i + 1;
+    if (ip > a.Nx) { sgn = sgn < 0 ? -sgn : sgn; ip -= a.Nx; }
+    const int jdst = a.Ny + jrow;
+    const int jsrc = (jrow == 0) ? a.Ny : ((yl == TPG_FACE) ? a.Ny - jrow + 1 : a.Ny - jrow);
+    const long long kbase = a.plane * (k + a.Hz - 1);
+    c[kbase + (long long)a.sx * (jdst + a.Hy - 1) + (i + a.Hx - 1)] =
+        (T)sgn * c[kbase + (long long)a.sx * (jsrc + a.Hy - 1) + (ip + a.Hx - 1)];
+}
+
+// ---- periodic west/east halos over every row and level of the parent ---------------------------
+struct PerArgs { int Nx, Hx, sx; long long nrows; int nfields; };
+struct PtrTable { void* ptr[TPG_MAX_FIELDS]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_periodic_x(PtrTable pt, PerArgs a)
+{
+    // item = (row, h): copies c[Nx-Hx+1+h] -> c[1-Hx+h] and c[1+h] -> c[Nx+1+h]
+    long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long per_field = a.nrows * a.Hx;
+    if (item >= per_field * a.nfields) return;
+    int f = (int)(item / per_field);
+    item -= (long long)f * per_field;
+    long long row = item / a.Hx;
+    int h = (int)(item - row * a.Hx);
+    T* c = static_cast<T*>(pt.ptr[f]) + row * a.sx;
+    c[h] = c[a.Nx + h];
+    c[a.Hx + a.Nx + h] = c[a.Hx + h];
+}
+
+// ---- latitude-band message pack / unpack --------------------------------------------------------
+struct PackArgs { int sx, sy, nlev, Hy, row0; long long plane; int nfields; int chunk_elems; };
+
+template <typename V, bool PACK>
+__global__ __launch_bounds__(256) void k_pack(PtrTable pt, V* buffer, PackArgs a)
+{
+    // message layout: [field][level][Hy rows][sx]; one item = one V (16 B or one element)
+    long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per_level = (long long)a.Hy * a.sx / a.chunk_elems;
+    const long long per_field = per_level * a.nlev;
+    if (item >= per_field * a.nfields) return;
+    int f = (int)(item / per_field);
+    long long r = item - (long long)f * per_field;
+    int lev = (int)(r / per_level);
+    long long w = r - (long long)lev * per_level;                  // chunk inside the Hy x sx slab
+    V* field = static_cast<V*>(pt.ptr[f]) + ((long long)a.plane * lev + (long long)a.sx * a.row0) / a.chunk_elems + w;
+    if (PACK) buffer[item] = *field;
+    else *field = buffer[item];
+}
+
+// ---- synthetic fill ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_synthetic(T* c, uint64_t seed, double sentinel, Geom g)
+{
+    long long n = g.plane * (g.Nz + 2 * g.Hz);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long k = idx / g.plane, rem = idx - k * g.plane;
+        int j = (int)(rem / g.sx), i = (int)(rem - (long long)j * g.sx);
+        bool interior = i >= g.Hx && i < g.Hx + g.Nx && j >= g.Hy && j < g.Hy + g.Ny && k >= g.Hz && k < g.Hz + g.Nz;
+        double v = sentinel;
+        if (interior) {
+            uint64_t h = splitmix64(seed ^ splitmix64((uint64_t)idx));
+            v = ((double)(h >> 11) + 0.5) * 0x1p-52 - 1.0;          // uniform in (-1, 1), never 0
+        }
+        c[idx] = (T)v;
+    }
+}
+
+int check_fields(void* const fields[], int nfields)
+{
+    if (!fields || nfields < 1) { tpg::set_error("no fields"); return TPG_ERR_INVALID_ARGUMENT; }
+    for (int f = 0; f < nfields; ++f)
+        if (!fields[f]) { tpg::set_error("null field %d", f); return TPG_ERR_INVALID_ARGUMENT; }
+    return TPG_OK;
+}
+
+template <typename T, int W>
+int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                 const Geom& g, int kstart, int kcount, hipStream_t s)
+{
+    bool vec = (g.Hx % W == 0) && (g.Nx % W == 0);
+    for (int f = 0; f < n && vec; ++f) vec = ((uintptr_t)fields[f] % 16) == 0;
+
+    FieldTable ft;
+    ZipArgs a;
+    a.Nx = g.Nx; a.Ny = g.Ny; a.Hx = g.Hx; a.Hy = g.Hy; a.Hz = g.Hz; a.sx = g.sx; a.plane = g.plane;
+    a.kstart = kstart; a.kcount = kcount;
+    a.nchunks = vec ? g.Nx / W : g.Nx;
+    a.fix0 = vec ? (g.Nx / 2) / W : g.Nx / 2;      // first chunk / element (0-based) holding an i > Nx/2
+    ft.nfields = n;
+    long long total = 0;
+    for (int f = 0; f < n; ++f) {
+        ft.ptr[f] = fields[f]; ft.xloc[f] = xloc[f]; ft.yloc[f] = yloc[f]; ft.sign[f] = sign[f];
+        ft.item0[f] = (int)total;
+        long long per_level = (long long)g.Hy * a.nchunks + (yloc[f] == TPG_CENTER ? a.nchunks - a.fix0 : 0);
+        total += per_level * kcount;
+        if (total >= (1ll << 31)) { tpg::set_error("zipper batch too large for 32-bit item index"); return TPG_ERR_UNSUPPORTED; }
+    }
+    ft.item0[n] = (int)total;
+    if (total == 0) return TPG_OK;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (vec) hipLaunchKernelGGL((k_zipper_vec<T, W>), grid, dim3(256), 0, s, ft, a);
+    else     hipLaunchKernelGGL((k_zipper_scalar<T>), grid, dim3(256), 0, s, ft, a);
+    return tpg::launch_status("k_zipper");
+}
+
+}  // namespace
+
+extern "C" {
+
+int tpg_zipper_fill(void* const fields[], int nfields, const int8_t xloc[], const int8_t yloc[],
+                    const int32_t sign[], int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
+                    int kstart, int kcount, int ft, void* stream)
+{
+    int rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft);
+    if (rc) return rc;
+    if ((rc = check_fields(fields, nfields))) return rc;
+    if (!xloc || !yloc || !sign) { tpg::set_error("null location/sign table"); return TPG_ERR_INVALID_ARGUMENT; }
+    for (int f = 0; f < nfields; ++f)
+        if ((xloc[f] != TPG_CENTER && xloc[f] != TPG_FACE) || (yloc[f] != TPG_CENTER && yloc[f] != TPG_FACE)) {
+            // _fill_north_halo! has methods for the four (x,y) location pairs only (:140-155)
+            tpg::set_error("field %d: no zipper method for location (%d,%d)", f, xloc[f], yloc[f]);
+            return TPG_ERR_INVALID_ARGUMENT;
+        }
+    if (kcount < 0 || kstart < 1 - Hz || kstart + kcount - 1 > Nz + Hz) {
+        tpg::set_error("level range %d:%d outside %d:%d", kstart, kstart + kcount - 1, 1 - Hz, Nz + Hz);
+        return TPG_ERR_INVALID_ARGUMENT;
+    }
+    if (kcount == 0 || Hy == 0) return TPG_OK;
+    Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
+    hipStream_t s = tpg::as_stream(stream);
+    for (int f0 = 0; f0 < nfields; f0 += TPG_MAX_FIELDS) {
+        int n = nfields - f0 < TPG_MAX_FIELDS ? nfields - f0 : TPG_MAX_FIELDS;
+        rc = (ft == TPG_F64) ? zipper_batch<double, 2>(fields + f0, n, xloc + f0, yloc + f0, sign + f0, g, kstart, kcount, s)
+                             : zipper_batch<float, 4>(fields + f0, n, xloc + f0, yloc + f0, sign + f0, g, kstart, kcount, s);
+        if (rc) return rc;
+    }
+    return TPG_OK;
+}
+
+int tpg_periodic_x_fill(void* const fields[], int nfields, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
+                        int ft, void* stream)
+{
+    int rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft);
+    if (rc) return rc;
+    if ((rc = check_fields(fields, nfields))) return rc;
+    if (Hx == 0) return TPG_OK;
+    Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
+    hipStream_t s = tpg::as_stream(stream);
+    for (int f0 = 0; f0 < nfields; f0 += TPG_MAX_FIELDS) {
+        int n = nfields - f0 < TPG_MAX_FIELDS ? nfields - f0 : TPG_MAX_FIELDS;
+        PtrTable pt;
+        for (int f = 0; f < n; ++f) pt.ptr[f] = fields[f0 + f];
+        PerArgs a{ Nx, Hx, g.sx, (long long)g.sy * (Nz + 2 * Hz), n };
+        long long total = a.nrows * Hx * n;
+        dim3 grid((unsigned)((total + 255) / 256));
+        if (ft == TPG_F64) hipLaunchKernelGGL(k_periodic_x<double>, grid, dim3(256), 0, s, pt, a);
+        else               hipLaunchKernelGGL(k_periodic_x<float>, grid, dim3(256), 0, s, pt, a);
+        if ((rc = tpg::launch_status("k_periodic_x"))) return rc;
+    }
+    return TPG_OK;
+}
+
+int tpg_fill_halo_regions(void* const fields[], int nfields, const int8_t xloc[], const int8_t yloc[],
+                          const int32_t sign[], int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
+                          int north_is_zipper, int ft, void* stream)
+{
+    int rc = TPG_OK;
+    if (north_is_zipper)
+        rc = tpg_zipper_fill(fields, nfields, xloc, yloc, sign, Nx, Ny, Nz, Hx, Hy, Hz, 1, Nz, ft, stream);
+    if (rc) return rc;
+    return tpg_periodic_x_fill(fields, nfields, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream);
+}
+
+size_t tpg_y_halo_buffer_elems(int nfields, int Nx, int Nz, int Hx, int Hy, int Hz)
+{
+    if (nfields < 0 || Nx < 0 || Nz < 0 || Hx < 0 || Hy < 0 || Hz < 0) return 0;
+    return (size_t)nfields * (size_t)(Nx + 2 * Hx) * (size_t)Hy * (size_t)(Nz + 2 * Hz);
+}
+
+static int pack_common(void* const fields[], int nfields, void* buffer, int side, bool pack,
+                       int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream)
+{
+    int rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft);
+    if (rc) return rc;
+    if ((rc = check_fields(fields, nfields))) return rc;
+    if (!buffer) { tpg::set_error("null message buffer"); return TPG_ERR_INVALID_ARGUMENT; }
+    if (side != 0 && side != 1) { tpg::set_error("side must be 0 (south) or 1 (north)"); return TPG_ERR_INVALID_ARGUMENT; }
+    if (nfields > TPG_MAX_FIELDS) { tpg::set_error("at most %d fields per message", TPG_MAX_FIELDS); return TPG_ERR_UNSUPPORTED; }
+    if (Hy == 0) return TPG_OK;
+    Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
+    // 0-based parent row of the slab: pack reads interior rows next to the side, unpack writes halo rows
+    int row0 = pack ? (side == 0 ? Hy : Ny) : (side == 0 ? 0 : Ny + Hy);
+    const size_t esz = ft == TPG_F64 ? 8 : 4;
+    const int per16 = (int)(16 / esz);
+    bool vec = ((uintptr_t)buffer % 16 == 0) && (g.sx % per16 == 0);
+    PtrTable pt;
+    for (int f = 0; f < nfields; ++f) { pt.ptr[f] = fields[f]; vec = vec && ((uintptr_t)fields[f] % 16 == 0); }
+    PackArgs a{ g.sx, g.sy, Nz + 2 * Hz, Hy, row0, g.plane, nfields, vec ? per16 : 1 };
+    long long total = (long long)nfields * a.nlev * Hy * g.sx / a.chunk_elems;
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t s = tpg::as_stream(stream);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (vec) {
+        if (pack) hipLaunchKernelGGL((k_pack<u32x4, true>), grid, dim3(256), 0, s, pt, static_cast<u32x4*>(buffer), a);
+        else      hipLaunchKernelGGL((k_pack<u32x4, false>), grid, dim3(256), 0, s, pt, static_cast<u32x4*>(buffer), a);
+    } else if (ft == TPG_F64) {
+        if (pack) hipLaunchKernelGGL((k_pack<double, true>), grid, dim3(256), 0, s, pt, static_cast<double*>(buffer), a);
+        else      hipLaunchKernelGGL((k_pack<double, false>), grid, dim3(256), 0, s, pt, static_cast<double*>(buffer), a);
+    } else {
+        if (pack) hipLaunchKernelGGL((k_pack<float, true>), grid, dim3(256), 0, s, pt, static_cast<float*>(buffer), a);
+        else      hipLaunchKernelGGL((k_pack<float, false>), grid, dim3(256), 0, s, pt, static_cast<float*>(buffer), a);
+    }
+    return tpg::launch_status("k_pack");
+}
+
+int tpg_pack_y_halo(void* const fields[], int nfields, void* buffer, int side,
+                    int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream)
+{
+    return pack_common(fields, nfields, buffer, side, true, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream);
+}
+
+int tpg_unpack_y_halo(void* const fields[], int nfields, const void* buffer, int side,
+                      int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream)
+{
+    return pack_common(fields, nfields, const_cast<void*>(buffer), side, false, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream);
+}
+
+int tpg_fill_synthetic(void* field, uint64_t seed, double halo_sentinel,
+                       int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream)
+{
+    int rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft);
+    if (rc) return rc;
+    if (!field) { tpg::set_error("null field"); return TPG_ERR_INVALID_ARGUMENT; }
+    Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
+    hipStream_t s = tpg::as_stream(stream);
+    if (ft == TPG_F64) hipLaunchKernelGGL(k_synthetic<double>, dim3(256 * 16), dim3(256), 0, s, static_cast<double*>(field), seed, halo_sentinel, g);
+    else               hipLaunchKernelGGL(k_synthetic<float>, dim3(256 * 16), dim3(256), 0, s, static_cast<float*>(field), seed, halo_sentinel, g);
+    return tpg::launch_status("k_synthetic");
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+"""Fields on a TripolarGrid and fill_halo_regions!: host-side mirror of the Field constructor
+override (src/tripolar_grid_extensions.jl:57-80, src/distributed_tripolar_grid.jl:159-198) and of
+the halo-fill entry that reaches _fill_north_halo! (src/zipper_boundary_condition.jl:146-155).
+
+Field data is one torch tensor of shape (Nz'+2Hz, Ny+2Hy, Nx+2Hx) in HBM whose memory is the
+`parent` of the reference's OffsetArray (i fastest).  fill_halo_regions batches every field of
+one geometry into ONE zipper launch + one periodic-x launch (tpg_fill_halo_regions).
+"""
+import ctypes as C
+from typing import Iterable, Optional
+
+import torch
+
+from . import _lib
+from .boundary_conditions import (Center, Face, FieldBoundaryConditions, PeriodicBoundaryCondition,
+                                  ZipperBoundaryCondition, HaloCommunicationBoundaryCondition,
+                                  is_zipper, sign)
+from .grids import is_tripolar
+
+
+def _loc_code(L):
+    if L is Center:
+        return _lib.TPG_CENTER
+    if L is Face:
+        return _lib.TPG_FACE
+    return None          # Nothing: reduced dimension
+
+
+class Field:
+    """Field((LX, LY, LZ), grid::TRG; boundary_conditions, data)
+
+    If the supplied north boundary condition is not already a Zipper, it is replaced by
+    ZipperBoundaryCondition(sign(LX, LY)) -- -1 on (Face,Center) / (Center,Face), +1 otherwise
+    (tripolar_grid_extensions.jl:49-53,65-67).  On a distributed grid only the last rank gets the
+    zipper; the other ranks' north side, and every seam, are neighbour communication
+    (distributed_tripolar_grid.jl:171,177-185).
+    """
+
+    def __init__(self, loc, grid, data=None, boundary_conditions="default", name=None):
+        if not is_tripolar(grid):
+            raise TypeError("Field: grid must be a TripolarGrid")
+        LX, LY, LZ = loc
+        self.loc = (LX, LY, LZ)
+        self.grid = grid
+        self.name = name
+        g = getattr(grid, "underlying_grid", grid)
+        self.Nx, self.Ny = g.Nx, g.Ny
+        self.Hx, self.Hy = g.Hx, g.Hy
+        if LZ is None:                       # reduced in z (e.g. bottom_height: (Center, Center, Nothing))
+            self.Nz, self.Hz = 1, 0
+        else:
+            self.Nz = g.Nz + (1 if LZ is Face else 0)   # Bounded z: Nz+1 faces
+            self.Hz = g.Hz
+        shape = (self.Nz + 2 * self.Hz, self.Ny + 2 * self.Hy, self.Nx + 2 * self.Hx)
+        if data is None:
+            data = torch.zeros(shape, dtype=g.dtype, device=g.device)
+        else:
+            # validate_field_data
+            if tuple(data.shape) != shape or not data.is_contiguous() or data.device != g.device:
+                raise ValueError(f"field data must be a contiguous {shape} tensor on {g.device}")
+        self.data = data
+
+        arch = g.architecture
+        distributed = getattr(arch, "is_distributed", False)
+        last_rank = (not distributed) or arch.local_rank == arch.ranks[1] - 1
+        if boundary_conditions is None:
+            self.boundary_conditions = None      # isnothing(old_bcs): kept as is (:62-63)
+        else:
+            old = FieldBoundaryConditions(west=PeriodicBoundaryCondition(), east=PeriodicBoundaryCondition()) \
+                if isinstance(boundary_conditions, str) else boundary_conditions
+            old.validate((LX, LY, LZ))       # validate_boundary_conditions (:60)
+            default_zipper = ZipperBoundaryCondition(sign(LX, LY))
+            north, south = old.north, old.south
+            if distributed:
+                r = arch.local_rank
+                if r > 0:
+                    south = HaloCommunicationBoundaryCondition(r, r - 1)
+                north = (old.north if is_zipper(old.north) else default_zipper) if last_rank \
+                    else HaloCommunicationBoundaryCondition(r, r + 1)
+            else:
+                north = old.north if is_zipper(old.north) else default_zipper
+            self.boundary_conditions = FieldBoundaryConditions(
+                west=old.west, east=old.east, south=south, north=north, top=old.top, bottom=old.bottom)
+
+    # --- convenience mirroring Oceananigans' interior / set! ---------------------------------
+    def interior(self):
+        """interior(field): view indexed [k-1, j-1, i-1]"""
+        return self.data[self.Hz:self.Hz + self.Nz, self.Hy:self.Hy + self.Ny, self.Hx:self.Hx + self.Nx]
+
+    def nodes(self):
+        """(λ, φ) of the field's horizontal location on the interior, each (Ny, Nx)"""
+        g = getattr(self.grid, "underlying_grid", self.grid)
+        suffix = ("f" if self.loc[0] is Face else "c") + ("f" if self.loc[1] is Face else "c")
+        return g.interior("lambda_" + suffix), g.interior("phi_" + suffix)
+
+    def set_(self, value):
+        """set!(field, value): a number, a tensor broadcastable to the interior, or f(λ, φ, z)"""
+        inter = self.interior()
+        if callable(value):
+            g = getattr(self.grid, "underlying_grid", self.grid)
+            lam, phi = self.nodes()
+            if self.loc[2] is None:
+                z = torch.zeros(1, dtype=g.dtype, device=g.device)
+            else:
+                zz = g.z_faces if self.loc[2] is Face else g.z_centers
+                z = zz[self.Hz:self.Hz + self.Nz]
+            value = value(lam[None, :, :].to(inter.dtype), phi[None, :, :].to(inter.dtype), z[:, None, None])
+        inter.copy_(torch.as_tensor(value, dtype=inter.dtype, device=inter.device).expand_as(inter))
+        return self
+
+    def __repr__(self):
+        names = tuple("Nothing" if L is None else L.__name__ for L in self.loc)
+        north = None if self.boundary_conditions is None else self.boundary_conditions.north
+        return f"Field{names} on {self.Nx}×{self.Ny}×{self.Nz} tripolar grid, north: {north}"
+
+
+def set_(field, value):
+    return field.set_(value)
+
+
+def interior(field):
+    return field.interior()
+
+
+def CenterField(grid, **kw):
+    return Field((Center, Center, Center), grid, **kw)
+
+
+def XFaceField(grid, **kw):
+    return Field((Face, Center, Center), grid, **kw)
+
+
+def YFaceField(grid, **kw):
+    return Field((Center, Face, Center), grid, **kw)
+
+
+def ZFaceField(grid, **kw):
+    return Field((Center, Center, Face), grid, **kw)
+
+
+# -------------------------------------------------------------------------------------------------
+# fill_halo_regions!
+# -------------------------------------------------------------------------------------------------
+def _groups(fields):
+    groups = {}
+    for f in fields:
+        if f.boundary_conditions is None:
+            continue
+        key = (f.data.dtype, f.data.device, f.Nx, f.Ny, f.Nz, f.Hx, f.Hy, f.Hz, id(f.grid))
+        groups.setdefault(key, []).append(f)
+    return groups.values()
+
+
+def _tables(fs):
+    xl, yl, sg = [], [], []
+    for f in fs:
+        x, y = _loc_code(f.loc[0]), _loc_code(f.loc[1])
+        north = f.boundary_conditions.north
+        if is_zipper(north) and (x is None or y is None):
+            # _fill_north_halo! has methods for the four (x, y) location pairs only (:140-155)
+            raise TypeError(f"no zipper method for a field at {f.loc}")
+        xl.append(0 if x is None else x)
+        yl.append(0 if y is None else y)
+        sg.append(int(north.condition) if is_zipper(north) else 1)
+    n = len(fs)
+    return (C.c_int8 * n)(*xl), (C.c_int8 * n)(*yl), (C.c_int32 * n)(*sg)
+
+
+def fill_halo_regions(fields, *, exchange=None):
+    """fill_halo_regions!(fields...) on a tripolar grid.
+
+    Order (pinned by test/test_zipper_boundary_conditions.jl:42-45):
+    zipper fold on the north side (serial grid or last rank) -> periodic x (fills corners) ->
+    on a distributed grid the y-seam exchange of Hy rows with the neighbour ranks.
+    `exchange` overrides the transport (used by the CPU/gloo tests of the host logic).
+    """
+    if isinstance(fields, Field):
+        fields = [fields]
+    fields = list(fields)
+    lib = _lib.lib()
+    for fs in _groups(fields):
+        f0 = fs[0]
+        g = getattr(f0.grid, "underlying_grid", f0.grid)
+        arch = g.architecture
+        zip_fs = [f for f in fs if is_zipper(f.boundary_conditions.north)]
+        ft = _lib.ft_of(f0.data.dtype)
+        geom = (f0.Nx, f0.Ny, f0.Nz, f0.Hx, f0.Hy, f0.Hz)
+        with torch.cuda.device(f0.data.device):
+            stream = _lib.current_stream_ptr(f0.data.device)
+            if zip_fs:
+                xl, yl, sg = _tables(zip_fs)
+                _lib.check(lib.tpg_zipper_fill(_lib.ptr_table([f.data for f in zip_fs]), len(zip_fs), xl, yl, sg,
+                                               *geom, 1, f0.Nz, ft, stream))
+            _lib.check(lib.tpg_periodic_x_fill(_lib.ptr_table([f.data for f in fs]), len(fs), *geom, ft, stream))
+        if getattr(arch, "is_distributed", False) and arch.ranks[1] > 1:
+            from .distributed import exchange_y_halos
+            exchange_y_halos(fs, arch, transport=exchange)
+    return None
