@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- TripolarGrid metric precompute + zipper halo fill at 1/10 deg x 75 levels on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input, resident in HBM:
+  (1) tpg_build_grid : coordinates + 12 staggered metrics of this rank's latitude band
+                       (N = 1: the whole 3600 x 1800 globe, Float64, halo 4) -> 20 padded arrays;
+  (2) fill_halo_regions! of the 4 synthetic 3600 x 1800 x 75 Float64 fields c(CC,+1) u(FC,-1)
+      v(CF,-1) zeta(FF,+1): zipper fold (ONE batched launch; north rank only) + periodic x
+      (+ for N > 1 the y-seam exchange of Hy rows with the neighbour ranks over RCCL send/recv).
+N > 1 is WEAK scaling: every rank keeps a 3600 x 1800 x 75 band of a 3600 x (1800 N) x 75 global
+tripolar grid (latitude bands, src/distributed_tripolar_grid.jl); no data-path collective.
+
+value = horizontal grid cells of all ranks / step time (max over ranks).  `roofline` is the zipper
+kernel (the HBM-bound kernel BASELINE.json's north_star sets the 70 % target on); the precompute
+kernel, which dominates the step time but is FP64-transcendental bound, is reported beside it.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NX, NY, NZ, H = 3600, 1800, 75, 4
+SPECS = [("c", 0, 0, 1), ("u", 1, 0, -1), ("v", 0, 1, -1), ("zeta", 1, 1, 1)]   # name, xloc, yloc, sign
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (datasheet)
+
+
+def zipper_algorithmic_bytes(nx, nz, hy, s=8):
+    """CF/FF fields Nx*Nz*Hy*2*s; CC/FC add the row-Ny substitution (Nx/2)*Nz*2*s"""
+    per_field = {}
+    for name, xl, yl, _ in SPECS:
+        b = nx * nz * hy * 2 * s
+        if yl == 0:
+            b += (nx // 2) * nz * 2 * s
+        per_field[name] = b
+    return per_field
+
+
+def cpu_baseline(threads):
+    """The oracle (CPU restatement, kind "port") timed on this host on a bounded sample of the same
+    workload: the full 3600x1800 grid build, and the 4-field zipper on a (3600, 64, 75) stand-in
+    (the fold touches only the top Hy+1 rows of each level, so bytes per level are identical)."""
+    import numpy as np
+    from oracle import oracle
+    oracle.set_threads(threads)
+    oracle.build_grid((360, 180, 1))                              # warm the library
+    t0 = time.perf_counter()
+    oracle.build_grid((NX, NY, 1))
+    t_build = time.perf_counter() - t0
+    ny_s = 64
+    size, halo = (NX, ny_s, NZ), (H, H, H)
+    fields = [np.random.default_rng(i).uniform(-1, 1, (NZ + 2 * H, ny_s + 2 * H, NX + 2 * H)) for i in range(4)]
+    for f, (_, xl, yl, sg) in zip(fields, SPECS):
+        oracle.zipper_fill(f, xl, yl, sg, size, halo)             # warm-up
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for f, (_, xl, yl, sg) in zip(fields, SPECS):
+            oracle.zipper_fill(f, xl, yl, sg, size, halo)
+    t_zip = (time.perf_counter() - t0) / reps
+    zbytes = sum(zipper_algorithmic_bytes(NX, NZ, H).values())
+    oracle.set_threads(1)
+    return {
+        "value": NX * NY / (t_build + t_zip), "unit": "cells/s", "cores": threads, "kind": "port",
+        "sample": f"oracle/tpg_oracle.c, {threads} thread(s): full 3600x1800 Float64 grid build ({t_build:.3f} s) + "
+                  f"4-field zipper on a 3600x64x75 stand-in ({t_zip * 1e3:.2f} ms, same bytes per level)",
+        "precompute_cells_per_s": NX * NY / t_build, "zipper_GBps": zbytes / t_zip / 1e9,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import orthogonalsphericalshellgrids.jl_amd as osg
+    from orthogonalsphericalshellgrids.jl_amd import _lib
+    from orthogonalsphericalshellgrids.jl_amd.distributed import exchange_y_halos
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    lib = _lib.lib()
+    halo = (H, H, H)
+    gsize = (NX, NY * world, NZ)                                   # weak scaling: 1800 rows per rank
+    if world > 1:
+        arch = osg.Distributed(osg.GPU(local_rank), osg.Partition(y=world), local_rank=rank)
+        jstart, jend = osg.local_row_range(gsize[1], arch)
+    else:
+        arch, jstart, jend = osg.GPU(local_rank), 1, NY
+    north_rank = rank == world - 1
+
+    # ---- resident inputs / outputs -------------------------------------------------------------
+    p = _lib.TpgParams(gsize[0], gsize[1], gsize[2], H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F64, jstart, jend, 0)
+    rows = jend - jstart + 1 + 2 * H
+    out = [torch.empty((rows, NX + 2 * H), dtype=torch.float64, device=dev) for _ in _lib.ARRAY_NAMES]
+    out_ptrs = _lib.ptr_table(out)
+    ws = torch.empty(int(lib.tpg_build_grid_workspace_bytes(C.byref(p))), dtype=torch.uint8, device=dev)
+    shape = (NZ + 2 * H, NY + 2 * H, NX + 2 * H)
+    fields = []
+    for fid, _ in enumerate(SPECS):
+        f = torch.empty(shape, dtype=torch.float64, device=dev)
+        _lib.check(lib.tpg_fill_synthetic(f.data_ptr(), 0x5EED + fid + 16 * rank, 12345.0, NX, NY, NZ, H, H, H, _lib.TPG_F64, None))
+        fields.append(f)
+    fptrs = _lib.ptr_table(fields)
+    n = len(SPECS)
+    xl = (C.c_int8 * n)(*[s[1] for s in SPECS]); yl = (C.c_int8 * n)(*[s[2] for s in SPECS]); sg = (C.c_int32 * n)(*[s[3] for s in SPECS])
+    geom = (NX, NY, NZ, H, H, H)
+
+    class BandField:                                                # what exchange_y_halos needs of a Field
+        def __init__(self, data):
+            self.data, self.Nx, self.Ny, self.Nz, self.Hx, self.Hy, self.Hz = data, NX, NY, NZ, H, H, H
+    band_fields = [BandField(f) for f in fields]
+
+    stream = _lib.current_stream_ptr(dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def step(marks=None):
+        if marks is not None: marks[0].record()
+        _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
+        if marks is not None: marks[1].record()
+        if north_rank:
+            _lib.check(lib.tpg_zipper_fill(fptrs, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F64, stream))
+        if marks is not None: marks[2].record()
+        _lib.check(lib.tpg_periodic_x_fill(fptrs, n, *geom, _lib.TPG_F64, stream))
+        if world > 1:
+            exchange_y_halos(band_fields, arch)
+        if marks is not None: marks[3].record()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    marks = [[ev() for _ in range(4)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(marks[k])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)      # ms
+    t_build, t_zip, t_rest = avg(0, 1), avg(1, 2), avg(2, 3)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        cells = NX * NY * world
+        zb = zipper_algorithmic_bytes(NX, NZ, H)
+        zbytes = sum(zb.values())
+        band_cells = (jend - jstart + 1 + 2 * H) * (NX + 2 * H)
+        line = {
+            "metric": "grid-cells/s metric precompute + zipper halo-fill GB/s, 1/10°×75z",
+            "value": cells / (elapsed / args.steps), "unit": "cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "TripolarGrid 1/10deg metric precompute (3600x1800 per rank, Float64, halo 4) + "
+                                   "fill_halo_regions! of 4 fields c/u/v/zeta (3600x1800x75 per rank): zipper + periodic-x"
+                                   + (" + RCCL y-seam exchange" if world > 1 else ""),
+                       "global_size": list(gsize), "local_size": [NX, NY, NZ], "halo": [H, H, H], "fields": [s[0] for s in SPECS],
+                       "parallelism": f"latitude-bands x{world}"},
+            "precompute_cells_per_s": NX * NY / (t_build * 1e-3),
+            "precompute_ms": t_build, "zipper_ms": t_zip, "periodic_and_exchange_ms": t_rest,
+            "zipper_GBps": zbytes / (t_zip * 1e-3) / 1e9 if north_rank else None,
+        }
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("k_zipper_vec_bytes_per_launch")
+        if north_rank:
+            line["roofline"] = {"kernel": "k_zipper_vec<double,2> (4 fields, 75 levels, one launch)", "bound": "hbm",
+                                "achieved": zbytes / (t_zip * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": zbytes / (t_zip * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                                "algorithmic_bytes_per_launch": zbytes, "launch_ms": t_zip}
+        flops = 3500.0 * NX * NY                                    # ~3.5 kflop FP64 per cell
+        line["roofline_precompute"] = {
+            "kernel": "tpg_build_grid (k_tables + k_cells + k_halos + k_south)", "bound": "hbm",
+            "achieved": 160.0 * band_cells / (t_build * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+            "algorithmic_bytes_per_launch": 160 * band_cells,
+            "note": "FP64-transcendental bound in practice: ~%.1f TFLOP/s of the %.1f TFLOP/s vector FP64 peak at ~3.5 kflop/cell"
+                    % (flops / (t_build * 1e-3) / 1e12, FP64_VALU_PEAK_TFLOPS)}
+        if world == 1 and not args.no_cpu_baseline:
+            threads = 1
+            line["cpu_baseline"] = cpu_baseline(threads)
+        print(json.dumps(line, ensure_ascii=False))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # a `-m gpu` run without a device must fail loudly, not skip: the product path is HIP-only
+    pass
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def kats():
+    import json
+    with open(os.path.join(GOLDEN, "reference_kats.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def osg():
+    import orthogonalsphericalshellgrids.jl_amd as m
+    return m
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device (there is no CPU fallback)"
+    torch.cuda.set_device(0)
+    return torch.device("cuda", 0)

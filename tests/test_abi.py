@@ -1,0 +1,89 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/tripolar_hip.h
+declares; argument validation (which precedes any device work) mirrors the reference's
+ArgumentErrors.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tripolar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tpg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_all_exported_and_bound(osg):
+    lib = osg._lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tripolar_hip.h but not exported"
+        assert n in osg._lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(osg._lib.SIGNATURES) == names
+
+
+def test_version_and_status_strings(osg):
+    lib = osg._lib.lib()
+    assert lib.tpg_version() == 100
+    assert b"even" in lib.tpg_status_string(-2)
+    assert lib.tpg_status_string(0) == b"ok"
+
+
+def _params(osg, **kw):
+    d = dict(Nx=60, Ny=30, Nz=1, Hx=4, Hy=4, Hz=4, south=-80.0, npl=55.0, fpl=70.0, R=6371e3, ft=1, jstart=1, jend=30)
+    d.update(kw)
+    return osg._lib.TpgParams(d["Nx"], d["Ny"], d["Nz"], d["Hx"], d["Hy"], d["Hz"], d["south"], d["npl"], d["fpl"],
+                              d["R"], d["ft"], d["jstart"], d["jend"], 0)
+
+
+def test_build_grid_argument_errors_without_device_work(osg):
+    lib = osg._lib.lib()
+    out = (C.c_void_p * 20)(*([1 << 20] * 20))          # never dereferenced: validation fails first
+    p = _params(osg, Nx=61)
+    assert lib.tpg_build_grid(C.byref(p), out, None, 0, None) == -2          # odd Nlambda (tripolar_grid.jl:81-83)
+    assert b"even" in lib.tpg_last_error()
+    p = _params(osg, jstart=5, jend=31)
+    assert lib.tpg_build_grid(C.byref(p), out, None, 0, None) == -3          # band outside the grid
+    p = _params(osg, ft=7)
+    assert lib.tpg_build_grid(C.byref(p), out, None, 0, None) == -1
+    p = _params(osg)
+    assert lib.tpg_build_grid(C.byref(p), out, None, 0, None) == -4          # no workspace
+    assert lib.tpg_build_grid_workspace_bytes(C.byref(p)) >= 8 * (4 * 60 + 4 * 30 + 5 * 5)
+    p = _params(osg, Hy=40)
+    assert lib.tpg_build_grid(C.byref(p), out, None, 0, None) == -5          # halo larger than the grid
+
+
+def test_zipper_argument_errors_without_device_work(osg):
+    lib = osg._lib.lib()
+    fields = (C.c_void_p * 1)(1 << 20)
+    xl, yl, sg = (C.c_int8 * 1)(0), (C.c_int8 * 1)(0), (C.c_int32 * 1)(1)
+    assert lib.tpg_zipper_fill(fields, 1, xl, yl, sg, 11, 10, 1, 4, 4, 4, 1, 1, 1, None) == -2
+    xl2 = (C.c_int8 * 1)(3)
+    assert lib.tpg_zipper_fill(fields, 1, xl2, yl, sg, 10, 10, 1, 4, 4, 4, 1, 1, 1, None) == -1   # no method for this location
+    assert lib.tpg_zipper_fill(fields, 1, xl, yl, sg, 10, 10, 1, 4, 4, 4, 1, 9, 1, None) == -1    # levels outside the parent
+    assert lib.tpg_zipper_fill(None, 0, xl, yl, sg, 10, 10, 1, 4, 4, 4, 1, 1, 1, None) == -1
+    assert lib.tpg_y_halo_buffer_elems(4, 3600, 75, 4, 4, 4) == 4 * 3608 * 4 * 83
+
+
+def test_product_has_no_cpu_path(osg):
+    """without a HIP device the host API must fail loudly instead of computing on the CPU"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        osg.TripolarGrid(size=(60, 30, 1))
+    with pytest.raises(RuntimeError, match="HIP-only"):
+        osg.TripolarGrid(osg.CPU(), size=(60, 30, 1))
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".jl")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.replace("oracle/ as test infrastructure", ""), os.path.join(dirpath, f)

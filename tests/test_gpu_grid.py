@@ -1,0 +1,159 @@
+"""GPU parity of the TripolarGrid metric precompute (tpg_build_grid) against the oracle.
+Tolerance stated by BASELINE.json north_star: <= 1e-12 relative on Float64 metrics.  By
+construction (tests/../csrc/tpg_math.hpp) the device arithmetic is the same IEEE operation
+sequence as the oracle's, so the expected outcome is bit-identity; both are asserted."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import A, interior, max_rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12     # relative, Float64 metrics (north_star)
+TOL32 = 0.0     # Float32 grids: Float64 pipeline rounded once at the end -> identical roundings
+
+
+def compare(grid, ref, tol=TOL):
+    worst, ndiff = 0.0, 0
+    for name, r in ref.items():
+        got = getattr(grid, name).cpu().numpy()
+        assert got.shape == r.shape and got.dtype == r.dtype, name
+        w, n = max_rel_err(got, r)
+        worst, ndiff = max(worst, w), ndiff + n
+    assert worst <= tol, f"max relative error {worst:.3e} over {ndiff} differing elements"
+    return ndiff
+
+
+CASES = [
+    dict(size=(60, 30, 1)),                                                            # config 1 (README)
+    dict(size=(4, 5, 1), first_pole_longitude=75, north_poles_latitude=35),            # runtests.jl:10-14 (fold reads row 1)
+    dict(size=(10, 10, 1)),                                                            # zipper test grid (Nx % 4 != 0)
+    dict(size=(360, 180, 1), first_pole_longitude=75, north_poles_latitude=35),        # test_tripolar_grid.jl:59
+    dict(size=(62, 31, 2), halo=(3, 2, 1)),
+    dict(size=(64, 33, 1), halo=(1, 1, 1), southernmost_latitude=-75.5, radius=1.0),   # non-integer south: dd range path
+    dict(size=(128, 64, 1), halo=(7, 5, 2), north_poles_latitude=60, first_pole_longitude=-35.25),
+    dict(size=(8, 4, 1), halo=(4, 4, 1)),                                              # Ny == Hy: fold reaches the zero south halo
+]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=[str(c["size"]) for c in CASES])
+def test_parity_f64(osg, oracle, gpu, kw):
+    grid = osg.TripolarGrid(osg.GPU(0), torch.float64, **kw)
+    ndiff = compare(grid, oracle.build_grid(dtype=np.float64, **kw))
+    assert ndiff == 0, "Float64 arrays expected bit-identical to the oracle"
+
+
+@pytest.mark.parametrize("kw", CASES[:5], ids=[str(c["size"]) for c in CASES[:5]])
+def test_parity_f32(osg, oracle, gpu, kw):
+    grid = osg.TripolarGrid(osg.GPU(0), torch.float32, **kw)
+    assert grid.lambda_cc.dtype == torch.float32                                       # eltype(grid) == FT
+    compare(grid, oracle.build_grid(dtype=np.float32, **kw), TOL32)
+
+
+def test_config2_quarter_degree(osg, oracle, gpu):
+    """BASELINE config 2: 1/4 degree (1440x720x1) Float64 metric precompute"""
+    kw = dict(size=(1440, 720, 1))
+    oracle.set_threads(min(16, oracle.max_threads()))
+    ref = oracle.build_grid(**kw)
+    oracle.set_threads(1)
+    assert compare(osg.TripolarGrid(osg.GPU(0), **kw), ref) == 0
+
+
+def test_tenth_degree_full_parity_and_properties(osg, oracle, gpu):
+    """1/10 degree (3600x1800): full-array parity plus the size-independent properties"""
+    size = (3600, 1800, 75)
+    grid = osg.TripolarGrid(osg.GPU(0), size=size)
+    oracle.set_threads(min(16, oracle.max_threads()))
+    ref = oracle.build_grid(size)
+    oracle.set_threads(1)
+    assert compare(grid, ref) == 0
+    Nx, Ny, _ = size
+    for n in ("lambda_cc", "lambda_fc", "lambda_cf", "lambda_ff"):
+        a = grid.interior(n)
+        assert float(a.min()) >= 0 and float(a.max()) < 360
+    assert bool((grid.interior("lambda_ff")[:, 0] == 250.0).all()) and bool((grid.interior("lambda_ff")[:, Nx // 2] == 70.0).all())
+    assert float(grid.interior("phi_fc")[Ny - 1, 0]) == 55.0 and float(grid.interior("phi_fc")[Ny - 1, Nx // 2]) == 55.0
+    for n in ("phi_cc", "dx_cc", "dy_cc", "az_cc"):                                    # fold symmetry of row Ny
+        row = grid.interior(n)[Ny - 1]
+        assert torch.equal(row, row.flip(0))
+    for n in ("dx_cc", "dy_ff", "az_fc"):                                              # periodic x halos
+        a = getattr(grid, n)
+        assert torch.equal(a[:, :4], a[:, Nx:Nx + 4]) and torch.equal(a[:, Nx + 4:], a[:, 4:8])
+    assert osg.x_domain(grid) == (0, 360)
+    assert osg.y_domain(grid) == (float(ref["phi_ff"].min()), 90)
+
+
+def test_reference_readme_numbers_on_gpu(osg, gpu, kats):
+    """the reference's only numeric known answers, reproduced by the HIP path itself"""
+    k = kats["readme_60x30"]
+    size = tuple(k["size"])
+    g = osg.TripolarGrid(size=size)
+    R = osg.R_Earth
+    sig = lambda x: float(f"{float(x):.6g}")
+    Nx, Ny, _ = size
+    assert float(g.interior("lambda_ff")[Ny // 2, Nx // 2]) == k["center_lambda_phi"][0]
+    assert round(float(g.interior("phi_ff")[Ny // 2, Nx // 2]), 4) == k["center_lambda_phi"][1]
+    assert sig(np.rad2deg(float(g.interior("dx_cf")[14].sum())) / R) == k["longitude_extent_deg"]
+    assert sig(np.rad2deg(float(g.interior("dx_ff").min())) / R) == k["min_dlambda"]
+    assert sig(np.rad2deg(float(g.interior("dx_ff").max())) / R) == k["max_dlambda"]
+    assert sig(np.rad2deg(float(g.interior("dy_fc")[:, 15].sum())) / R) == k["latitude_extent_deg"]
+    assert sig(np.rad2deg(float(g.interior("dy_ff").min())) / R) == k["min_dphi"]
+    assert sig(np.rad2deg(float(g.interior("dy_ff").max())) / R) == k["max_dphi"]
+
+
+def test_golden_restatement_vectors(osg, gpu):
+    import os
+    from conftest import GOLDEN
+    gold = np.load(os.path.join(GOLDEN, "restatement_60x30_f64.npz"))
+    g = osg.TripolarGrid(size=(60, 30, 1))
+    for name in gold.files:
+        assert np.array_equal(getattr(g, name).cpu().numpy(), gold[name], equal_nan=True), name
+
+
+@pytest.mark.parametrize("R", [2, 3, 8])
+def test_latitude_bands_equal_slices_of_the_global_grid(osg, oracle, gpu, R):
+    """config 4 partitioning (distributed_tripolar_grid.jl:41-49,112-120): every rank's band,
+    built independently on the device, equals rows jstart-Hy:jend+Hy of the global grid."""
+    size, halo = (96, 48, 1), (4, 4, 4)
+    glob = oracle.build_grid(size, halo=halo)
+    for r in range(R):
+        arch = osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=r)
+        g = osg.TripolarGrid(arch, size=size, halo=halo)
+        jstart, jend = osg.local_row_range(size[1], arch)
+        assert g.Ny == jend - jstart + 1 and g.jrange == (jstart, jend)
+        assert g.topology[1] is (osg.RightConnected if r == 0 else osg.FullyConnected)     # :75
+        for name, ref in glob.items():
+            got = getattr(g, name).cpu().numpy()
+            assert np.array_equal(got, ref[jstart - 1:jend + 2 * halo[1]], equal_nan=True), (r, name)
+
+
+def test_with_halo_and_reconstruct(osg, oracle, gpu):
+    g = osg.TripolarGrid(size=(60, 30, 1))
+    g2 = osg.with_halo((2, 3, 1), g)                                                   # with_halo.jl:5-23
+    assert g2.halo_size == (2, 3, 1) and g2.size == g.size
+    ref = oracle.build_grid((60, 30, 1), halo=(2, 3, 1))
+    assert compare(g2, ref) == 0
+    arch = osg.Distributed(osg.GPU(0), osg.Partition(y=2), local_rank=1)
+    band = osg.TripolarGrid(arch, size=(60, 30, 1))
+    full = osg.reconstruct_global_grid(band)                                           # distributed_tripolar_grid.jl:201-226
+    assert full.size == (60, 30, 1) and compare(full, oracle.build_grid((60, 30, 1))) == 0
+
+
+def test_conformal_mapping_kept_verbatim(osg, gpu):
+    g = osg.TripolarGrid(size=(4, 5, 1), z=(0, 1), first_pole_longitude=75, north_poles_latitude=35,
+                         southernmost_latitude=-80)
+    assert g.Nx == 4 and g.Ny == 5 and g.Nz == 1                                       # runtests.jl:19-21
+    cm = g.conformal_mapping
+    assert cm.first_pole_longitude == 75 and cm.north_poles_latitude == 35 and cm.southernmost_latitude == -80
+    assert isinstance(cm.first_pole_longitude, int)
+
+
+def test_workspace_too_small_is_an_error(osg, gpu):
+    lib = osg._lib.lib()
+    p = osg._lib.TpgParams(60, 30, 1, 4, 4, 4, -80.0, 55.0, 70.0, 6371e3, 1, 1, 30, 0)
+    arrs = [torch.empty((38, 68), dtype=torch.float64, device=gpu) for _ in range(20)]
+    ws = torch.empty(64, dtype=torch.uint8, device=gpu)
+    rc = lib.tpg_build_grid(C.byref(p), osg._lib.ptr_table(arrs), ws.data_ptr(), ws.numel(), None)
+    assert rc == -4

@@ -1,0 +1,179 @@
+"""GPU parity of the Zipper halo fill (tpg_zipper_fill / tpg_fill_halo_regions) against the
+oracle: bit-exact on the whole padded array (integer index map + sign)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import synthetic_field
+
+pytestmark = pytest.mark.gpu
+
+LOCS = [(0, 0), (1, 0), (0, 1), (1, 1)]
+
+
+def loc_types(osg, xl, yl):
+    return (osg.Face if xl else osg.Center, osg.Face if yl else osg.Center, osg.Center)
+
+
+def make_fields(osg, grid, specs, rng, dtype):
+    fs, hosts = [], []
+    for xl, yl, sg in specs:
+        f = osg.Field(loc_types(osg, xl, yl), grid,
+                      boundary_conditions=osg.FieldBoundaryConditions(north=osg.ZipperBoundaryCondition(sg)))
+        h = rng.uniform(-1, 1, tuple(f.data.shape)).astype(dtype)
+        f.data.copy_(torch.from_numpy(h))
+        fs.append(f); hosts.append(h)
+    return fs, hosts
+
+
+def test_reference_zipper_testset(osg, gpu, kats):
+    """test/test_zipper_boundary_conditions.jl:5-45 through the product API"""
+    k = kats["zipper_10x10"]
+    grid = osg.TripolarGrid(size=tuple(k["size"]))
+    Nx, Ny, _ = grid.size
+    Hx, Hy, Hz = grid.halo_size
+    c, u, v = osg.CenterField(grid), osg.XFaceField(grid), osg.YFaceField(grid)
+    for f, name in ((c, "c"), (u, "u"), (v, "v")):
+        north = f.boundary_conditions.north
+        assert isinstance(north.classification, osg.Zipper)                    # :14-16
+        assert north.condition == k["default_sign"][name]                      # :21-23
+        osg.set_(f, 1)
+    osg.fill_halo_regions(c); osg.fill_halo_regions(u); osg.fill_halo_regions(v)
+    north = lambda f: f.data[Hz, Ny + Hy:Ny + 2 * Hy, :]
+    e = k["constant_one"]
+    assert bool((north(c) == e["c_north_halo"]).all())                         # :35
+    assert bool((north(v) == e["v_north_halo"]).all())                         # :36
+    assert bool((north(u)[:, Hx + 1:Hx + Nx - 1] == e["u_north_halo_i_2_to_Nx_minus_1"]).all())   # :39-40
+    assert bool((north(u)[:, Hx] == e["u_north_halo_i_1"]).all())              # :42,44
+    assert bool((north(u)[:, Hx + Nx] == e["u_north_halo_i_Nx_plus_1"]).all())  # :43,45
+
+
+def test_reference_row_symmetry_testset(osg, gpu):
+    """:47-72: bottom_height-like reduced field, c(x), u(x) rows"""
+    grid = osg.TripolarGrid(size=(10, 10, 1))
+    bottom = osg.Field((osg.Center, osg.Center, None), grid)                   # (Center, Center, Nothing)
+    bottom.set_(torch.rand(10, 10, dtype=torch.float64, device=gpu))
+    osg.fill_halo_regions(bottom)
+    row = bottom.interior()[0, 9]
+    assert torch.equal(row, row.flip(0))                                       # :54
+    c, u = osg.CenterField(grid), osg.XFaceField(grid)
+    c.set_(lambda x, y, z: x); u.set_(lambda x, y, z: x)
+    osg.fill_halo_regions([c, u])
+    crow, urow = c.interior()[0, 9], u.interior()[0, 9]
+    assert torch.equal(crow, crow.flip(0))                                     # :65
+    assert torch.equal(urow[1:5], -urow[6:10].flip(0))                         # :68-72
+
+
+GEOMS = [((10, 10, 1), (4, 4, 4)), ((60, 30, 3), (4, 4, 4)), ((62, 31, 2), (3, 2, 1)),   # odd Hx -> scalar kernel
+         ((256, 40, 4), (4, 4, 2)), ((1000, 50, 2), (4, 4, 4)), ((130, 20, 3), (2, 5, 0)),
+         ((6, 7, 1), (4, 4, 1)), ((4, 4, 2), (4, 4, 1))]
+
+
+@pytest.mark.parametrize("size,halo", GEOMS, ids=[f"{s}-{h}" for s, h in GEOMS])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fill_halo_regions_parity(osg, oracle, gpu, size, halo, dtype):
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    grid = osg.TripolarGrid(osg.GPU(0), tdt, size=size, halo=halo)
+    specs = [(xl, yl, sg) for xl, yl in LOCS for sg in (1, -1)]
+    fs, hosts = make_fields(osg, grid, specs, np.random.default_rng(5), dtype)
+    osg.fill_halo_regions(fs)                                                  # one batched launch
+    for f, h, (xl, yl, sg) in zip(fs, hosts, specs):
+        oracle.fill_halo_regions(h, xl, yl, sg, size, halo)
+        assert np.array_equal(f.data.cpu().numpy(), h), (xl, yl, sg)
+
+
+def test_zipper_only_and_level_range(osg, oracle, gpu):
+    """tpg_zipper_fill leaves x halos and unlisted levels untouched; kstart/kcount may address halo levels"""
+    size, halo = (64, 20, 5), (4, 4, 2)
+    lib = osg._lib.lib()
+    rng = np.random.default_rng(3)
+    for xl, yl in LOCS:
+        h = rng.uniform(-1, 1, (5 + 4, 20 + 8, 64 + 8))
+        d = torch.from_numpy(h).to(gpu)
+        for kstart, kcount in ((2, 3), (-1, 9)):
+            want = h.copy()
+            oracle.zipper_fill(want, xl, yl, -1, size, halo, kstart, kcount)
+            got = d.clone()
+            rc = lib.tpg_zipper_fill(osg._lib.ptr_table([got]), 1, (C.c_int8 * 1)(xl), (C.c_int8 * 1)(yl), (C.c_int32 * 1)(-1),
+                                     *size, *halo, kstart, kcount, 1, None)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(got.cpu().numpy(), want), (xl, yl, kstart)
+
+
+def test_more_fields_than_one_launch_holds(osg, oracle, gpu):
+    size, halo = (32, 12, 2), (4, 4, 4)
+    grid = osg.TripolarGrid(size=size, halo=halo)
+    specs = [(f % 2, (f // 2) % 2, 1 if f % 3 else -1) for f in range(37)]     # > 2 x TPG_MAX_FIELDS
+    fs, hosts = make_fields(osg, grid, specs, np.random.default_rng(11), np.float64)
+    osg.fill_halo_regions(fs)
+    for f, h, (xl, yl, sg) in zip(fs, hosts, specs):
+        oracle.fill_halo_regions(h, xl, yl, sg, size, halo)
+        assert np.array_equal(f.data.cpu().numpy(), h)
+
+
+def test_unaligned_base_pointer_takes_the_scalar_kernel(osg, oracle, gpu):
+    size, halo = (32, 12, 2), (4, 4, 4)
+    shape = (2 + 8, 12 + 8, 32 + 8)
+    n = int(np.prod(shape))
+    raw = torch.zeros(n + 1, dtype=torch.float64, device=gpu)
+    view = raw[1:]                                                              # 8-byte aligned only
+    h = np.random.default_rng(2).uniform(-1, 1, shape)
+    view.copy_(torch.from_numpy(h).flatten())
+    lib = osg._lib.lib()
+    ptr = (C.c_void_p * 1)(view.data_ptr())
+    assert lib.tpg_zipper_fill(ptr, 1, (C.c_int8 * 1)(1), (C.c_int8 * 1)(0), (C.c_int32 * 1)(-1), *size, *halo, 1, 2, 1, None) == 0
+    torch.cuda.synchronize()
+    oracle.zipper_fill(h, 1, 0, -1, size, halo)
+    assert np.array_equal(view.cpu().numpy().reshape(shape), h)
+
+
+def test_synthetic_fill_matches_host_twin(osg, gpu):
+    size, halo = (24, 10, 3), (4, 4, 2)
+    lib = osg._lib.lib()
+    for dt, tdt, ft in ((np.float64, torch.float64, 1), (np.float32, torch.float32, 0)):
+        d = torch.empty((3 + 4, 10 + 8, 24 + 8), dtype=tdt, device=gpu)
+        assert lib.tpg_fill_synthetic(d.data_ptr(), 0x5EED + 1, 12345.0, *size, *halo, ft, None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy(), synthetic_field(0x5EED + 1, 12345.0, size, halo, dt))
+
+
+def test_config3_tenth_degree_75_levels(osg, oracle, gpu):
+    """BASELINE config 3: (3600,1800,75), halo 4, Float64, fields c(CC,+1) u(FC,-1) v(CF,-1) zeta(FF,+1),
+    splitmix64 interior / sentinel halos.  Full-size checks:
+      * bit-exact parity of every row the fold can touch (rows Ny-Hy..Ny+Hy, all levels) against the
+        oracle run on that slab as a short (Ny' = 2Hy+1) field -- the fold only looks Hy rows down;
+      * everything below is untouched (checksum of the raw bits before/after);
+      * x halos and z-halo levels of the north rows keep the sentinel (zipper only, no periodic pass).
+    """
+    size, halo = (3600, 1800, 75), (4, 4, 4)
+    (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
+    lib = osg._lib.lib()
+    specs = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]
+    shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
+    fields = []
+    for fid, _ in enumerate(specs):
+        d = torch.empty(shape, dtype=torch.float64, device=gpu)
+        assert lib.tpg_fill_synthetic(d.data_ptr(), 0x5EED + fid, 12345.0, *size, *halo, 1, None) == 0
+        fields.append(d)
+    top = slice(Ny - 1, Ny + 2 * Hy)            # parent rows of logical rows Ny-Hy .. Ny+Hy
+    before = [f[:, top].cpu().numpy() for f in fields]
+    low_sum = [int(f[:, :Ny - 1].view(torch.int64).sum()) for f in fields]
+    n = len(specs)
+    rc = lib.tpg_zipper_fill(osg._lib.ptr_table(fields), n, (C.c_int8 * n)(*[s[0] for s in specs]),
+                             (C.c_int8 * n)(*[s[1] for s in specs]), (C.c_int32 * n)(*[s[2] for s in specs]),
+                             *size, *halo, 1, Nz, 1, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    slab_size = (Nx, Hy + 1, Nz)                # short field whose top row is the global row Ny
+    for f, b, (xl, yl, sg), ls in zip(fields, before, specs, low_sum):
+        # slab rows: [Ny-Hy .. Ny] interior-like + Hy halo rows; pad Hy dummy south-halo rows for the oracle
+        want = np.concatenate([np.zeros_like(b[:, :Hy]), b], axis=1)
+        oracle.zipper_fill(want, xl, yl, sg, slab_size, halo)
+        got = f[:, top].cpu().numpy()
+        assert np.array_equal(got, want[:, Hy:]), (xl, yl, sg)
+        assert int(f[:, :Ny - 1].view(torch.int64).sum()) == ls
+        assert bool((f[:, Ny + Hy:, :Hx] == 12345.0).all()) and bool((f[:Hz, Ny + Hy:] == 12345.0).all())
+        assert not bool((f[Hz:Hz + Nz, Ny + Hy:, Hx:Hx + Nx] == 12345.0).any())     # every halo cell of the fold written

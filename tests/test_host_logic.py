@@ -1,0 +1,84 @@
+"""Host-side mirror of the reference's dispatch glue: zipper sign policy, validation, partition rule."""
+import pytest
+
+
+def test_zipper_boundary_condition_type(osg):
+    bc = osg.ZipperBoundaryCondition()
+    assert isinstance(bc.classification, osg.Zipper) and bc.condition == 1     # zipper_boundary_condition.jl:52
+    assert osg.ZipperBoundaryCondition(-1).condition == -1
+    assert osg.bc_str(bc) == "Zipper"                                          # :56
+    assert osg.apply_y_north_bc(None, None, bc) is None                        # :64
+
+
+@pytest.mark.parametrize("side", ["south", "west", "east", "top", "bottom"])
+def test_zipper_is_north_only(osg, side):
+    z = osg.ZipperBoundaryCondition()
+    assert osg.validate_boundary_condition_location(z, osg.Center, "north") is None
+    with pytest.raises(ValueError, match="north only"):                        # :58-62
+        osg.validate_boundary_condition_location(z, osg.Face, side)
+
+
+def test_sign_table(osg):
+    C, F = osg.Center, osg.Face                                                # tripolar_grid_extensions.jl:49-53
+    assert osg.sign(F, F) == 1 and osg.sign(C, C) == 1
+    assert osg.sign(F, C) == -1 and osg.sign(C, F) == -1
+    assert osg.sign(None, C) == 1
+
+
+def test_regularize_by_name(osg):
+    class G:  # serial grid stand-in
+        architecture = None
+    bcs = osg.FieldBoundaryConditions()
+    for name, s in (("u", -1), ("v", -1), ("c", 1), ("T", 1), ("w", 1)):       # :32
+        north = osg.regularize_field_boundary_conditions(bcs, G(), name).north
+        assert osg.is_zipper(north) and north.condition == s
+
+
+def test_regularize_distributed_only_last_rank(osg):
+    class G:
+        def __init__(self, r):
+            self.architecture = osg.Distributed(osg.GPU(), osg.Partition(y=4), local_rank=r)
+    bcs = osg.FieldBoundaryConditions()
+    for r in range(4):                                                         # distributed_tripolar_grid.jl:143-147
+        north = osg.regularize_field_boundary_conditions(bcs, G(r), "u").north
+        assert osg.is_zipper(north) == (r == 3)
+
+
+def test_partition_rule(osg):
+    assert osg.local_sizes(1800, 8) == [225] * 8                               # config 4
+    assert osg.local_sizes(10, 3) == [3, 3, 4]
+    assert osg.local_sizes(10, 2, [4, 6]) == [4, 6]
+    with pytest.raises(ValueError):
+        osg.local_sizes(10, 2, [4, 5])
+    arch = lambda r: osg.Distributed(osg.GPU(), osg.Partition(y=8), local_rank=r)
+    assert osg.local_row_range(1800, arch(0)) == (1, 225)                      # :47-48
+    assert osg.local_row_range(1800, arch(7)) == (1576, 1800)
+    assert osg.local_row_range(1801, arch(7)) == (1576, 1801)                  # last rank always ends at Ny
+
+
+def test_x_partitioning_is_rejected(osg):
+    arch = osg.Distributed(osg.GPU(), osg.Partition(x=2, y=1), local_rank=0)
+    with pytest.raises(ValueError, match="Y-partitioning"):                    # :28-31
+        osg.TripolarGrid(arch, size=(60, 30, 1))
+
+
+def test_odd_longitude_rejected_before_device(osg):
+    with pytest.raises(ValueError, match="should be even"):
+        osg.TripolarGrid(size=(61, 30, 1))
+
+
+def test_exchange_plan(osg):
+    from orthogonalsphericalshellgrids.jl_amd.distributed import SeamMessage, NORTH, SOUTH
+    assert osg.exchange_plan(0, 1) == []
+    assert osg.exchange_plan(0, 4) == [SeamMessage(NORTH, 1)]
+    assert osg.exchange_plan(2, 4) == [SeamMessage(NORTH, 3), SeamMessage(SOUTH, 1)]
+    assert osg.exchange_plan(3, 4) == [SeamMessage(SOUTH, 2)]                  # north side of the last rank = zipper
+
+
+def test_unicode_property_aliases(osg):
+    from orthogonalsphericalshellgrids.jl_amd.grids import _UNICODE_ALIASES
+    import unicodedata
+    assert _UNICODE_ALIASES[unicodedata.normalize("NFKC", "Δxᶜᶜᵃ")] == "dx_cc"
+    assert _UNICODE_ALIASES[unicodedata.normalize("NFKC", "φᶠᶜᵃ")] == "phi_fc"
+    assert _UNICODE_ALIASES[unicodedata.normalize("NFKC", "Azᶜᶠᵃ")] == "az_cf"
+    assert len(_UNICODE_ALIASES) == 20
