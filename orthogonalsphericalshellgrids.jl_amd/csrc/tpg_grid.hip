@@ -21,6 +21,7 @@
 // analytic function.
 #include "tpg_common.hpp"
 #include "tpg_math.hpp"
+#include <stdlib.h>
 
 using namespace tpgm;
 
@@ -233,14 +234,18 @@ __device__ __forceinline__ double quad_area(V3 a, V3 b, V3 c, V3 d)
     return A / 2;
 }
 
-template <typename T>
+// NT = streaming store: the 20 output arrays (1 GB at 1/10 deg) are written once and not re-read by
+// this launch sequence; a plain store would park them as dirty lines in L2 / Infinity Cache and
+// the NEXT kernel on the stream (typically a halo fill) would pay for their eviction.
+template <typename T, bool NT = false>
 __device__ __forceinline__ void put(const OutPtrs& o, int q, long long off, double v)
 {
-    static_cast<T*>(o.p[q])[off] = (T)v;
+    T* p = static_cast<T*>(o.p[q]) + off;
+    if (NT) __builtin_nontemporal_store((T)v, p); else *p = (T)v;
 }
 
 // ---- K1: interior cells ------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void k_cells(GridK g, OutPtrs o)
 {
     const int nbx = (g.Nx + 255) / 256;
@@ -270,17 +275,145 @@ __global__ __launch_bounds__(256) void k_cells(GridK g, OutPtrs o)
     double azff = quad_area(cartesian(cc_sw), cartesian(cc_s), cartesian(cc), cartesian(cc_w)) * (R * R);   // :38-43
 
     long long off = (long long)(i + g.Hx - 1) + (long long)g.sx * (j - g.jstart + g.Hy);
-    put<T>(o, TPG_LAMBDA_CC, off, cc.lam); put<T>(o, TPG_LAMBDA_FC, off, fc.lam);
-    put<T>(o, TPG_LAMBDA_CF, off, cf.lam); put<T>(o, TPG_LAMBDA_FF, off, ff.lam);
-    put<T>(o, TPG_PHI_CC, off, cc.phi); put<T>(o, TPG_PHI_FC, off, fc.phi);
-    put<T>(o, TPG_PHI_CF, off, cf.phi); put<T>(o, TPG_PHI_FF, off, ff.phi);
-    put<T>(o, TPG_DX_CC, off, dxcc); put<T>(o, TPG_DX_FC, off, dxfc);
-    put<T>(o, TPG_DX_CF, off, dxcf); put<T>(o, TPG_DX_FF, off, dxff);
-    put<T>(o, TPG_DY_CC, off, dycc); put<T>(o, TPG_DY_CF, off, dycf);
-    put<T>(o, TPG_DY_FC, off, dyfc); put<T>(o, TPG_DY_FF, off, dyff);
-    put<T>(o, TPG_AZ_CC, off, azcc); put<T>(o, TPG_AZ_FC, off, azfc);
-    put<T>(o, TPG_AZ_CF, off, azcf); put<T>(o, TPG_AZ_FF, off, azff);
+    put<T, NT>(o, TPG_LAMBDA_CC, off, cc.lam); put<T, NT>(o, TPG_LAMBDA_FC, off, fc.lam);
+    put<T, NT>(o, TPG_LAMBDA_CF, off, cf.lam); put<T, NT>(o, TPG_LAMBDA_FF, off, ff.lam);
+    put<T, NT>(o, TPG_PHI_CC, off, cc.phi); put<T, NT>(o, TPG_PHI_FC, off, fc.phi);
+    put<T, NT>(o, TPG_PHI_CF, off, cf.phi); put<T, NT>(o, TPG_PHI_FF, off, ff.phi);
+    put<T, NT>(o, TPG_DX_CC, off, dxcc); put<T, NT>(o, TPG_DX_FC, off, dxfc);
+    put<T, NT>(o, TPG_DX_CF, off, dxcf); put<T, NT>(o, TPG_DX_FF, off, dxff);
+    put<T, NT>(o, TPG_DY_CC, off, dycc); put<T, NT>(o, TPG_DY_CF, off, dycf);
+    put<T, NT>(o, TPG_DY_FC, off, dyfc); put<T, NT>(o, TPG_DY_FF, off, dyff);
+    put<T, NT>(o, TPG_AZ_CC, off, azcc); put<T, NT>(o, TPG_AZ_FC, off, azfc);
+    put<T, NT>(o, TPG_AZ_CF, off, azcf); put<T, NT>(o, TPG_AZ_FF, off, azff);
 }
+
+// ---- K1 (marching form): one wave = 62 output columns x a strip of rows -----------------------
+// Every staggered point (lambda, phi) and what the metrics derive from it -- a = deg2rad(phi),
+// cos(a) for the haversines, the unit vector for the two quadrilateral areas -- is evaluated ONCE
+// by the lane that owns its column, kept in registers while the wave marches north, and handed to
+// the east / west neighbour lane with wave shuffles (no LDS allocation, no barrier).  Lanes 0 and
+// 63 are apron lanes (they only supply their neighbours), so a wave emits 62 columns.  Compared
+// with the thread-per-cell form this removes the 14 redundant point evaluations per cell and the
+// repeated cos / sind / cosd of shared points: ~65 instead of ~140 transcendental calls per cell.
+// The arithmetic of every value is unchanged (same operation sequence), so results are
+// bit-identical to k_cells.
+struct Pt  { double lam, phi, a, ca; };                 // FC / CF points
+struct PtX { double lam, phi, a, ca, X, Y, Z; };        // CC / FF points (+ unit vector)
+struct Nb  { double lam, a, ca; };                      // what a haversine needs of a neighbour
+struct NbX { double lam, a, ca, X, Y, Z; };
+
+__device__ __forceinline__ Pt make_pt(const GridK& g, int xl, int yl, int i, int j)
+{
+    LP p = coord(g, xl, yl, i, j);
+    Pt r; r.lam = p.lam; r.phi = p.phi; r.a = p.phi * kDeg2Rad; r.ca = cosD(r.a);
+    return r;
+}
+__device__ __forceinline__ PtX make_ptx(const GridK& g, int xl, int yl, int i, int j)
+{
+    LP p = coord(g, xl, yl, i, j);
+    PtX r; r.lam = p.lam; r.phi = p.phi; r.a = p.phi * kDeg2Rad; r.ca = cosD(r.a);
+    double sl, cl, sp, cp;
+    sincosd(p.lam, sl, cl);
+    sincosd(p.phi, sp, cp);
+    r.X = cl * cp; r.Y = sl * cp; r.Z = sp;             // lat_lon_to_cartesian(phi, lambda, 1)
+    return r;
+}
+__device__ __forceinline__ Nb nb_of(const Pt& p) { return Nb{ p.lam, p.a, p.ca }; }
+__device__ __forceinline__ Nb nb_of(const PtX& p) { return Nb{ p.lam, p.a, p.ca }; }
+__device__ __forceinline__ NbX nbx_of(const PtX& p) { return NbX{ p.lam, p.a, p.ca, p.X, p.Y, p.Z }; }
+__device__ __forceinline__ V3 v3_of(const PtX& p) { return V3{ p.X, p.Y, p.Z }; }
+__device__ __forceinline__ V3 v3_of(const NbX& p) { return V3{ p.X, p.Y, p.Z }; }
+
+template <int DIR> __device__ __forceinline__ double shf(double v)
+{
+    return DIR > 0 ? __shfl_down(v, 1, 64) : __shfl_up(v, 1, 64);   // DIR>0: value of lane+1
+}
+template <int DIR> __device__ __forceinline__ Nb shf_nb(const Pt& p)
+{
+    return Nb{ shf<DIR>(p.lam), shf<DIR>(p.a), shf<DIR>(p.ca) };
+}
+template <int DIR> __device__ __forceinline__ NbX shf_nbx(const PtX& p)
+{
+    return NbX{ shf<DIR>(p.lam), shf<DIR>(p.a), shf<DIR>(p.ca), shf<DIR>(p.X), shf<DIR>(p.Y), shf<DIR>(p.Z) };
+}
+
+// haversine(x, y, R) with the per-point parts precomputed: x = first argument, y = second
+__device__ __forceinline__ double hav(double xlam, double xa, double xca, double ylam, double ya, double yca, double R)
+{
+    double dl = (ylam - xlam) * kDeg2Rad;
+    double dp = ya - xa;
+    double s1 = sinD(dp / 2), s2 = sinD(dl / 2);
+    double h = s1 * s1 + xca * yca * (s2 * s2);
+    double r = sqrt(h);
+    return 2 * (R * asinD(r != r ? r : (r < 1.0 ? r : 1.0)));
+}
+#define HAV(P, Q) hav((P).lam, (P).a, (P).ca, (Q).lam, (Q).a, (Q).ca, R)
+
+struct MarchArgs { int nwx, L; };
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void k_cells_march(GridK g, OutPtrs o, MarchArgs m)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int strip = wv / m.nwx;
+    const int xw = wv - strip * m.nwx;
+    const int jlo = g.jm_lo + strip * m.L;
+    if (jlo > g.jm_hi) return;                                     // whole wave exits together
+    const int jhi = min(jlo + m.L - 1, g.jm_hi);
+    int i = xw * 62 + lane;                                        // lanes 0 / 63: west / east apron
+    const bool emit = lane >= 1 && lane <= 62 && i <= g.Nx;
+    if (i > g.Nx + 1) i = g.Nx + 1;                                // idle lanes of the last window
+    const double R = g.R;
+
+    // prologue: FC, CC on row jlo-1; FF, CF on row jlo
+    Pt fcP = make_pt(g, 1, 0, i, jlo - 1), cfP = make_pt(g, 0, 1, i, jlo);
+    PtX ccP = make_ptx(g, 0, 0, i, jlo - 1), ffP = make_ptx(g, 1, 1, i, jlo);
+    NbX ccWP = shf_nbx<-1>(ccP);                                   // CC(i-1, jlo-1)
+    NbX ffEP = shf_nbx<+1>(ffP);                                   // FF(i+1, jlo)
+    Nb cfWP = shf_nb<-1>(cfP);                                     // CF(i-1, jlo)
+
+    for (int j = jlo; j <= jhi; ++j) {
+        Pt fc = make_pt(g, 1, 0, i, j), cf = make_pt(g, 0, 1, i, j + 1);
+        PtX cc = make_ptx(g, 0, 0, i, j), ff = make_ptx(g, 1, 1, i, j + 1);
+        Nb fcE = shf_nb<+1>(fc);                                   // FC(i+1, j)
+        NbX ccW = shf_nbx<-1>(cc);                                 // CC(i-1, j)
+        NbX ffE = shf_nbx<+1>(ff);                                 // FF(i+1, j+1)
+        Nb cfW = shf_nb<-1>(cf);                                   // CF(i-1, j+1)
+
+        // FC: e = fcE, c = fc, s = fcP | CC: c = cc, w = ccW, s = ccP, sw = ccWP
+        // FF: c = ffP, e = ffEP, n = ff, ne = ffE | CF: c = cfP, w = cfWP, n = cf
+        double dxcc = HAV(fcE, fc);            // tripolar_grid_utils.jl:13
+        double dxfc = HAV(cc, ccW);            // :14
+        double dxcf = HAV(ffEP, ffP);          // :15
+        double dxff = HAV(cfP, cfWP);          // :16
+        double dycc = HAV(cf, cfP);            // :18
+        double dyfc = HAV(ff, ffP);            // :19
+        double dycf = HAV(cc, ccP);            // :20
+        double dyff = HAV(fc, fcP);            // :21
+        double azcc = quad_area(v3_of(ffP), v3_of(ffEP), v3_of(ffE), v3_of(ff)) * (R * R);     // :23-28
+        double azfc = dyfc * dxfc;             // :34
+        double azcf = dycf * dxcf;             // :35
+        double azff = quad_area(v3_of(ccWP), v3_of(ccP), v3_of(cc), v3_of(ccW)) * (R * R);     // :38-43
+
+        if (emit) {
+            long long off = (long long)(i + g.Hx - 1) + (long long)g.sx * (j - g.jstart + g.Hy);
+            put<T, NT>(o, TPG_LAMBDA_CC, off, cc.lam); put<T, NT>(o, TPG_LAMBDA_FC, off, fc.lam);
+            put<T, NT>(o, TPG_LAMBDA_CF, off, cfP.lam); put<T, NT>(o, TPG_LAMBDA_FF, off, ffP.lam);
+            put<T, NT>(o, TPG_PHI_CC, off, cc.phi); put<T, NT>(o, TPG_PHI_FC, off, fc.phi);
+            put<T, NT>(o, TPG_PHI_CF, off, cfP.phi); put<T, NT>(o, TPG_PHI_FF, off, ffP.phi);
+            put<T, NT>(o, TPG_DX_CC, off, dxcc); put<T, NT>(o, TPG_DX_FC, off, dxfc);
+            put<T, NT>(o, TPG_DX_CF, off, dxcf); put<T, NT>(o, TPG_DX_FF, off, dxff);
+            put<T, NT>(o, TPG_DY_CC, off, dycc); put<T, NT>(o, TPG_DY_CF, off, dycf);
+            put<T, NT>(o, TPG_DY_FC, off, dyfc); put<T, NT>(o, TPG_DY_FF, off, dyff);
+            put<T, NT>(o, TPG_AZ_CC, off, azcc); put<T, NT>(o, TPG_AZ_FC, off, azfc);
+            put<T, NT>(o, TPG_AZ_CF, off, azcf); put<T, NT>(o, TPG_AZ_FF, off, azff);
+        }
+        fcP = fc; ccP = cc; ffP = ff; cfP = cf;
+        ccWP = ccW; ffEP = ffE; cfWP = cfW;
+    }
+}
+#undef HAV
 
 // ---- K2: halo cells of the 20 arrays ------------------------------------------------------------
 // x/y location of array q (order of enum tpg_array)
@@ -385,7 +518,40 @@ template <typename T>
 int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStream_t s)
 {
     dim3 grid1(((g.Nx + 255) / 256) * (g.jm_hi - g.jm_lo + 1));
-    hipLaunchKernelGGL(k_cells<T>, grid1, dim3(256), 0, s, g, o);
+    static const bool nt = getenv("TPG_BUILD_NT") ? atoi(getenv("TPG_BUILD_NT")) != 0 : true;
+    static const int variant = getenv("TPG_CELLS_VARIANT") ? atoi(getenv("TPG_CELLS_VARIANT")) : 1;
+    static const int strip_rows = getenv("TPG_CELLS_STRIP") ? atoi(getenv("TPG_CELLS_STRIP")) : 0;
+    if (variant == 1) {
+        // strips sized so that the whole grid is (just under) one resident round of waves:
+        // equal work per wave, no tail; short strips cost one extra point row each
+        MarchArgs m;
+        m.nwx = (g.Nx + 61) / 62;
+        const int nrows = g.jm_hi - g.jm_lo + 1;
+        int L = strip_rows;
+        if (L <= 0) {
+            static int resident_waves = 0;
+            if (!resident_waves) {
+                int dev = 0, cus = 256, blocks = 2;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_cells_march<T, true>, 256, 0);
+                if (blocks < 1) blocks = 1;
+                resident_waves = cus * blocks * 4;
+            }
+            int strips = resident_waves / m.nwx;
+            if (strips < 1) strips = 1;
+            L = (nrows + strips - 1) / strips;
+            if (L < 8) L = nrows < 8 ? nrows : 8;
+        }
+        m.L = L;
+        const int nstrips = (nrows + L - 1) / L;
+        const int nwaves = nstrips * m.nwx;
+        dim3 gridm((nwaves + 3) / 4);
+        if (nt) hipLaunchKernelGGL((k_cells_march<T, true>), gridm, dim3(256), 0, s, g, o, m);
+        else    hipLaunchKernelGGL((k_cells_march<T, false>), gridm, dim3(256), 0, s, g, o, m);
+    }
+    else if (nt) hipLaunchKernelGGL((k_cells<T, true>), grid1, dim3(256), 0, s, g, o);
+    else         hipLaunchKernelGGL((k_cells<T, false>), grid1, dim3(256), 0, s, g, o);
     int rc = tpg::launch_status("k_cells");
     if (rc) return rc;
     int nh = h.nA + h.nB + h.nC + h.nD;

@@ -173,6 +173,41 @@ TPG_DEV double cosd(double x)
     double c = kcos(h, l);
     return neg ? -c : c;
 }
+
+// sind(x) and cosd(x) together: both functions reduce x to the same distance t from the nearest
+// multiple of 90 (ties at 45+90k give t = 45 either way) and evaluate the sin- or cos-kernel on the
+// same double-double radian argument, so one reduction + one ksin + one kcos yields both values with
+// exactly the bits sind() and cosd() return separately (ksin is odd, kcos even, deg2rad_ext odd --
+// all exactly).
+TPG_DEV void sincosd(double x, double& sn, double& cs)
+{
+    double rx = csign(fmod360(x), x);
+    double r = absD(rx);
+    double sg = csign(1.0, rx);
+    // nearest multiple of 90 for sind (ties -> 90/270) and for cosd (ties -> 0/180/360)
+    int ms = r < 45.0 ? 0 : (r <= 135.0 ? 1 : (r < 225.0 ? 2 : (r <= 315.0 ? 3 : 4)));
+    int mc = r <= 45.0 ? 0 : (r < 135.0 ? 1 : (r <= 225.0 ? 2 : (r < 315.0 ? 3 : 4)));
+    double d = (double)(90 * ms) - r;                 // signed offset to sind's multiple
+    double t = absD(d);                                // == |90*mc - r| as well
+    double h, l;
+    deg2rad_ext(t, h, l);
+    double S = ksin(h, l), C = kcos(h, l);
+    double dsg = csign(1.0, d);                        // sign(90*ms - r)
+    switch (ms) {
+    case 0:  sn = sg * S; break;                       // ksin(d2r(rx))
+    case 1:  sn = sg * C; break;                       // copysign(kcos(d2r(90-r)), rx)
+    case 2:  sn = (dsg * sg) * S; break;               // ksin(d2r((180-r)*sign(rx))); r == 180 -> +-0
+    case 3:  sn = -(sg * C); break;                    // -copysign(kcos(d2r(270-r)), rx)
+    default: sn = -(sg * S); break;                    // ksin(d2r(rx - copysign(360, rx)))
+    }
+    switch (mc) {
+    case 0:  cs = C; break;                            // kcos(d2r(r))
+    case 1:  cs = csign(1.0, 90.0 - r) * S; break;     // ksin(d2r(90-r))   (+0 at r = 90)
+    case 2:  cs = -C; break;                           // -kcos(d2r(180-r))
+    case 3:  cs = csign(1.0, r - 270.0) * S; break;    // ksin(d2r(r-270))  (+0 at r = 270)
+    default: cs = C; break;                            // kcos(d2r(360-r))
+    }
+}
 TPG_DEV double tand(double x) { return sind(x) / cosd(x); }
 
 // ---- atan

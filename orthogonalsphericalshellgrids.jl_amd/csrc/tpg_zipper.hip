@@ -18,6 +18,7 @@
 // Geometries whose rows are not 16-B chunkable (odd Hx for f64, Hx or Nx not multiple of 4 for
 // f32, misaligned base pointers) run the scalar kernel (one element per item).
 #include "tpg_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,8 +27,8 @@ using tpg::Geom;
 struct FieldTable {
     void* ptr[TPG_MAX_FIELDS];
     int item0[TPG_MAX_FIELDS + 1];   // prefix sums of work items per field
-    int8_t xloc[TPG_MAX_FIELDS];
-    int8_t yloc[TPG_MAX_FIELDS];
+    int xloc[TPG_MAX_FIELDS];        // 32-bit so that a wave-uniform field index reads them with s_load
+    int yloc[TPG_MAX_FIELDS];
     int sign[TPG_MAX_FIELDS];
     int nfields;
 };
@@ -119,6 +120,70 @@ __global__ __launch_bounds__(256) void k_zipper_vec(FieldTable ft, ZipArgs a)
 #pragma unroll
     for (int e = 0; e < W; ++e) o[e] = out[e];
     *reinterpret_cast<vec_t*>(dst + (i - 1)) = o;
+}
+
+// ---- column kernel: one thread owns one 16-B column chunk of one (field, level) and folds ALL
+// Hy halo rows (+ the row-Ny substitution): the Hy (+2) independent 16-B loads are issued before
+// the first store, so a wave keeps (Hy+2) KiB in flight instead of 1 KiB -- the fold moves only
+// ~70 MB per launch, which makes it latency- rather than bandwidth-limited unless every wave
+// carries many outstanding requests.
+template <typename T, int W, int HY, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void k_zipper_cols(FieldTable ft, ZipArgs a)
+{
+    typedef typename Vec<T, W>::aligned_t vec_t;
+    typedef typename Vec<T, W>::loose_t lvec_t;
+    const int f = blockIdx.y;                                      // wave-uniform: table reads are scalar loads
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= a.kcount * a.nchunks) return;
+    const int xl = ft.xloc[f], yl = ft.yloc[f];
+    const int sgn = ft.sign[f];
+    T* __restrict__ c = static_cast<T*>(ft.ptr[f]);
+    const int kk = item / a.nchunks;
+    const int ch = item - kk * a.nchunks;
+    const int k = a.kstart + kk;
+    const int i = ch * W + 1;
+    T* lvl = c + a.plane * (k + a.Hz - 1) + a.Hx;                  // element (i = 1, parent row 0)
+    const long long sx = a.sx;
+    const int prow_ny = a.Ny + a.Hy - 1;                           // parent row of logical row Ny
+    const int ysh = (yl == TPG_FACE) ? 1 : 0;                      // source row Ny - j + ysh
+    const bool fix = (yl == TPG_CENTER) && (ch >= a.fix0);
+    // x-Face, first chunk: element i = 1 wraps to i' = 1 with |sign| (:73-75, :90-92); the mirrored
+    // window then starts one element into the east halo, whose (unused) value is replaced below
+    const bool wrap = (xl == TPG_FACE) && (ch == 0);
+
+    // mirrored source window: x-Center i' = Nx-i+1, x-Face i' = Nx-i+2 (one element to the right)
+    const int soff = a.Nx - i - W + 1 + (xl == TPG_FACE ? 1 : 0);
+    vec_t v[HY];
+    T w0[HY];
+#pragma unroll
+    for (int jr = 1; jr <= HY; ++jr) {
+        const T* row = lvl + sx * (prow_ny - jr + ysh);
+        const lvec_t* p = reinterpret_cast<const lvec_t*>(row + soff);
+        if (NTL) v[jr - 1] = __builtin_nontemporal_load(p); else v[jr - 1] = *p;
+        w0[jr - 1] = wrap ? row[0] : (T)0;
+    }
+    vec_t vf = {}, old = {};
+    if (fix) {
+        vf = *reinterpret_cast<const lvec_t*>(lvl + sx * prow_ny + soff);
+        old = *reinterpret_cast<const vec_t*>(lvl + sx * prow_ny + (i - 1));
+    }
+    const T s = (T)sgn, as = (T)(sgn < 0 ? -sgn : sgn);
+#pragma unroll
+    for (int jr = 1; jr <= HY; ++jr) {
+        vec_t o;
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = s * v[jr - 1][W - 1 - e];
+        if (wrap) o[0] = as * w0[jr - 1];
+        vec_t* q = reinterpret_cast<vec_t*>(lvl + sx * (prow_ny + jr) + (i - 1));
+        if (NTS) __builtin_nontemporal_store(o, q); else *q = o;
+    }
+    if (fix) {
+        // c[i,Ny] = ifelse(i > Nx/2, sign*c[i',Ny], c[i,Ny]) (:102,:135); i = 1 is never > Nx/2
+        vec_t o;
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = (i + e > a.Nx / 2) ? s * vf[W - 1 - e] : old[e];
+        *reinterpret_cast<vec_t*>(lvl + sx * prow_ny + (i - 1)) = o;
+    }
 }
 
 // ---- scalar kernel: any geometry / alignment ---------------------------------------------------
@@ -224,12 +289,37 @@ int check_fields(void* const fields[], int nfields)
     return TPG_OK;
 }
 
+template <typename T, int W, bool NTL, bool NTS>
+void launch_cols(int Hy, dim3 grid, hipStream_t s, const FieldTable& ft, const ZipArgs& a)
+{
+    switch (Hy) {
+    case 1: hipLaunchKernelGGL((k_zipper_cols<T, W, 1, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
+    case 2: hipLaunchKernelGGL((k_zipper_cols<T, W, 2, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
+    case 3: hipLaunchKernelGGL((k_zipper_cols<T, W, 3, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
+    case 4: hipLaunchKernelGGL((k_zipper_cols<T, W, 4, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
+    case 5: hipLaunchKernelGGL((k_zipper_cols<T, W, 5, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
+    case 6: hipLaunchKernelGGL((k_zipper_cols<T, W, 6, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
+    case 7: hipLaunchKernelGGL((k_zipper_cols<T, W, 7, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
+    default: hipLaunchKernelGGL((k_zipper_cols<T, W, 8, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
+    }
+}
+
+// tuning knob (tools/zipper_tune.py): TPG_ZIPPER_VARIANT = 0 row items, 1 columns, 2 columns + nontemporal
+// loads and stores, 3 nontemporal loads only, 4 nontemporal stores only
+int zipper_variant()
+{
+    const char* e = getenv("TPG_ZIPPER_VARIANT");
+    return e ? atoi(e) : 1;
+}
+
 template <typename T, int W>
 int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                  const Geom& g, int kstart, int kcount, hipStream_t s)
 {
     bool vec = (g.Hx % W == 0) && (g.Nx % W == 0);
     for (int f = 0; f < n && vec; ++f) vec = ((uintptr_t)fields[f] % 16) == 0;
+    const int variant = zipper_variant();
+    const bool cols = vec && g.Hy <= 8 && variant != 0;
 
     FieldTable ft;
     ZipArgs a;
@@ -242,15 +332,23 @@ int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t 
     for (int f = 0; f < n; ++f) {
         ft.ptr[f] = fields[f]; ft.xloc[f] = xloc[f]; ft.yloc[f] = yloc[f]; ft.sign[f] = sign[f];
         ft.item0[f] = (int)total;
-        long long per_level = (long long)g.Hy * a.nchunks + (yloc[f] == TPG_CENTER ? a.nchunks - a.fix0 : 0);
+        long long per_level = cols ? a.nchunks
+                                   : (long long)g.Hy * a.nchunks + (yloc[f] == TPG_CENTER ? a.nchunks - a.fix0 : 0);
         total += per_level * kcount;
         if (total >= (1ll << 31)) { tpg::set_error("zipper batch too large for 32-bit item index"); return TPG_ERR_UNSUPPORTED; }
     }
     ft.item0[n] = (int)total;
     if (total == 0) return TPG_OK;
     dim3 grid((unsigned)((total + 255) / 256));
-    if (vec) hipLaunchKernelGGL((k_zipper_vec<T, W>), grid, dim3(256), 0, s, ft, a);
-    else     hipLaunchKernelGGL((k_zipper_scalar<T>), grid, dim3(256), 0, s, ft, a);
+    if (cols) {
+        dim3 grid2((unsigned)(((long long)kcount * a.nchunks + 255) / 256), (unsigned)n);
+        if (variant == 2)      launch_cols<T, W, true, true>(g.Hy, grid2, s, ft, a);
+        else if (variant == 3) launch_cols<T, W, true, false>(g.Hy, grid2, s, ft, a);
+        else if (variant == 4) launch_cols<T, W, false, true>(g.Hy, grid2, s, ft, a);
+        else                   launch_cols<T, W, false, false>(g.Hy, grid2, s, ft, a);
+    }
+    else if (vec) hipLaunchKernelGGL((k_zipper_vec<T, W>), grid, dim3(256), 0, s, ft, a);
+    else          hipLaunchKernelGGL((k_zipper_scalar<T>), grid, dim3(256), 0, s, ft, a);
     return tpg::launch_status("k_zipper");
 }
 
