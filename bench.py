@@ -198,15 +198,15 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("k_zipper_vec_bytes_per_launch")
+                traffic = json.load(f).get("k_zipper_cols_bytes_per_launch")
         if north_rank:
-            line["roofline"] = {"kernel": "k_zipper_vec<double,2> (4 fields, 75 levels, one launch)", "bound": "hbm",
+            line["roofline"] = {"kernel": "k_zipper_cols<double,2,4> (4 fields x 75 levels, one launch)", "bound": "hbm",
                                 "achieved": zbytes / (t_zip * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": zbytes / (t_zip * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                                 "algorithmic_bytes_per_launch": zbytes, "launch_ms": t_zip}
         flops = 3500.0 * NX * NY                                    # ~3.5 kflop FP64 per cell
         line["roofline_precompute"] = {
-            "kernel": "tpg_build_grid (k_tables + k_cells + k_halos + k_south)", "bound": "hbm",
+            "kernel": "tpg_build_grid (k_tables + k_cells_march + k_halos + k_south)", "bound": "hbm",
             "achieved": 160.0 * band_cells / (t_build * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
             "algorithmic_bytes_per_launch": 160 * band_cells,
