@@ -1,0 +1,187 @@
+// tpg_batch.hpp -- straight-line ("batched") forms of the tpg_math.hpp functions.
+//
+// The metric kernel is FP64 latency-bound: at 2 waves/SIMD a chain of dependent v_fma_f64 leaves
+// the SIMD idle ~1/3 of the time, and the early-outs / range branches of the scalar functions cut
+// the code into small basic blocks the scheduler cannot interleave.  Each function here evaluates
+// N independent arguments in one basic block, stage by stage ("vertical" order), with selects
+// instead of branches.  Every output has EXACTLY the bits of the scalar function:
+//   * the msun early-outs (|x| < 2^-27, |x| >= 2^66, ...) are shortcuts, not different values: the
+//     general formula rounds to the same result there (argued next to each function);
+//   * where a scalar function genuinely takes another path (|x| > pi/4 in sin, |x| >= 0.5 in asin,
+//     deep cancellation in the pi/2 reduction) the batch form reports a `rare` flag and the caller
+//     re-evaluates through the scalar function.
+#pragma once
+#include "tpg_math.hpp"
+
+namespace tpgb {
+using namespace tpgm;
+
+#define TPG_UNROLL _Pragma("unroll")
+
+// ksin / kcos of x + y, elementwise (any N)
+template <int N> TPG_DEV void ksin_b(const double (&x)[N], const double (&y)[N], double (&out)[N])
+{
+    double z[N], r[N], v[N];
+    TPG_UNROLL for (int e = 0; e < N; ++e) z[e] = x[e] * x[e];
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], r[e], 2.75573137070700676789e-06);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], r[e], -1.98412698298579493134e-04);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], r[e], 8.33333333332248946124e-03);
+    TPG_UNROLL for (int e = 0; e < N; ++e) v[e] = z[e] * x[e];
+    TPG_UNROLL for (int e = 0; e < N; ++e)
+        out[e] = x[e] - ((z[e] * (0.5 * y[e] - v[e] * r[e]) - y[e]) - v[e] * -1.66666666666666324348e-01);
+}
+template <int N> TPG_DEV void kcos_b(const double (&x)[N], const double (&y)[N], double (&out)[N])
+{
+    double z[N], r[N];
+    TPG_UNROLL for (int e = 0; e < N; ++e) z[e] = x[e] * x[e];
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], r[e], -2.75573143513906633035e-07);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], r[e], 2.48015872894767294178e-05);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], r[e], -1.38888888888741095749e-03);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], r[e], 4.16666666666666019037e-02);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = z[e] * r[e];
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        double hz = 0.5 * z[e];
+        double w = 1.0 - hz;
+        out[e] = w + (((1.0 - w) - hz) + (z[e] * r[e] - x[e] * y[e]));
+    }
+}
+
+// sin(x) for |x| <= pi/4 (the haversine's half-differences).  tpgm::sinD returns x for
+// |x| < 2^-26: ksin(x, 0) = x - x^3/6 (1 - ...) rounds to x there (|x^2/6| < 2^-54), also for +-0.
+// rare: some |x| > pi/4 (seam-crossing longitude differences) -> caller uses tpgm::sinD.
+template <int N> TPG_DEV bool sin_small_b(const double (&x)[N], double (&out)[N])
+{
+    double y[N];
+    bool rare = false;
+    TPG_UNROLL for (int e = 0; e < N; ++e) { y[e] = 0.0; rare |= !(absD(x[e]) <= kPio4Hi); }
+    ksin_b<N>(x, y, out);
+    return rare;
+}
+
+// cos(a) through the first Cody-Waite step for every argument (n = 0 reproduces the direct
+// kcos(a, 0) of tpgm::cosD exactly: fn = +-0, y0 = a, y1 = 0).
+// rare: the reduction would need its 2nd iteration (a within 2^-16 relative of an odd multiple of
+// pi/2, e.g. the geographic pole phi = 90) -> caller uses tpgm::cosD.
+template <int N> TPG_DEV bool cos_b(const double (&a)[N], double (&out)[N])
+{
+    double fn[N], y0[N], y1[N], S[N], C[N];
+    bool rare = false;
+    TPG_UNROLL for (int e = 0; e < N; ++e) fn[e] = __builtin_rint(a[e] * kInvPio2);
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        double r = a[e] - fn[e] * kPio2_1;
+        double w = fn[e] * kPio2_1t;
+        y0[e] = r - w;
+        y1[e] = (r - y0[e]) - w;
+        rare |= (expo(a[e]) - expo(y0[e]) > 16);
+    }
+    ksin_b<N>(y0, y1, S);
+    kcos_b<N>(y0, y1, C);
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        int n = (int)fn[e];
+        double v = (n & 1) ? S[e] : C[e];
+        out[e] = ((n + 1) & 2) ? -v : v;
+    }
+    return rare;
+}
+
+// atan(x), all x (finite, +-Inf; NaN -> NaN).  The scalar early-outs are redundant value-wise:
+//  |x| < 2^-27: t - t (s1+s2) with s1+s2 ~ t^2/3 < 2^-55 rounds to t;
+//  |x| >= 2^66 (and Inf): t = -1/|x| is below half an ulp of pi/2, the formula gives RN(hi + lo) = hi.
+template <int N> TPG_DEV void atan_b(const double (&x)[N], double (&out)[N])
+{
+    double t[N], hi[N], lo[N], s[N];
+    bool direct[N];
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        double ax = absD(x[e]);
+        direct[e] = ax < 0.4375;
+        bool b0 = ax < 0.6875, b1 = ax < 1.1875, b2 = ax < 2.4375;
+        double num = b0 ? 2.0 * ax - 1.0 : (b2 ? (b1 ? ax - 1.0 : ax - 1.5) : -1.0);
+        double den = b0 ? 2.0 + ax : (b1 ? ax + 1.0 : (b2 ? 1.0 + 1.5 * ax : ax));
+        hi[e] = b0 ? 0x1.dac670561bb4fp-2 : (b1 ? 0x1.921fb54442d18p-1 : (b2 ? 0x1.f730bd281f69bp-1 : kPio2Hi));
+        lo[e] = b0 ? 0x1.a2b7f222f65e2p-56 : (b1 ? 0x1.1a62633145c07p-55 : (b2 ? 0x1.007887af0cbbdp-56 : kPio2Lo));
+        double q = num / den;
+        t[e] = direct[e] ? ax : q;
+    }
+    {
+        double z[N], w[N], s1[N], s2[N];
+        TPG_UNROLL for (int e = 0; e < N; ++e) { z[e] = t[e] * t[e]; w[e] = z[e] * z[e]; }
+        TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], 1.62858201153657823623e-02, 4.97687799461593236017e-02);
+                                                 s2[e] = fmaD(w[e], -3.65315727442169155270e-02, -5.83357013379057348645e-02); }
+        TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 6.66107313738753120669e-02);
+                                                 s2[e] = fmaD(w[e], s2[e], -7.69187620504482999495e-02); }
+        TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 9.09088713343650656196e-02);
+                                                 s2[e] = fmaD(w[e], s2[e], -1.11111104054623557880e-01); }
+        TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 1.42857142725034663711e-01);
+                                                 s2[e] = fmaD(w[e], s2[e], -1.99999999998764832476e-01); }
+        TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 3.33333333333329318027e-01);
+                                                 s2[e] = w[e] * s2[e]; }
+        TPG_UNROLL for (int e = 0; e < N; ++e) s[e] = z[e] * s1[e] + s2[e];
+    }
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        double ts = t[e] * s[e];
+        double r = direct[e] ? t[e] - ts : hi[e] - ((ts - lo[e]) - t[e]);
+        out[e] = csign(r, x[e]);
+    }
+}
+
+// asin(x) for |x| < 0.5.  tpgm::asinD returns x for |x| < 2^-26: x + x (p/q) with p/q ~ x^2/6
+// rounds to x there.  rare: some |x| >= 0.5 (edges longer than 60 degrees: the overwritten row
+// j = 1, toy grids) -> caller uses tpgm::asinD.
+template <int N> TPG_DEV bool asin_small_b(const double (&x)[N], double (&out)[N])
+{
+    double t[N], p[N], q[N];
+    bool rare = false;
+    TPG_UNROLL for (int e = 0; e < N; ++e) { t[e] = x[e] * x[e]; rare |= !(absD(x[e]) < 0.5); }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { p[e] = fmaD(t[e], 3.47933107596021167570e-05, 7.91534994289814532176e-04);
+                                             q[e] = fmaD(t[e], 7.70381505559019352791e-02, -6.88283971605453293030e-01); }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { p[e] = fmaD(t[e], p[e], -4.00555345006794114027e-02);
+                                             q[e] = fmaD(t[e], q[e], 2.02094576023350569471e+00); }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { p[e] = fmaD(t[e], p[e], 2.01212532134862925881e-01);
+                                             q[e] = fmaD(t[e], q[e], -2.40339491173441421878e+00); }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { p[e] = fmaD(t[e], p[e], -3.25565818622400915405e-01);
+                                             q[e] = fmaD(t[e], q[e], 1.0); }
+    TPG_UNROLL for (int e = 0; e < N; ++e) p[e] = fmaD(t[e], p[e], 1.66666666666666657415e-01);
+    TPG_UNROLL for (int e = 0; e < N; ++e) p[e] = t[e] * p[e];
+    TPG_UNROLL for (int e = 0; e < N; ++e) out[e] = x[e] + x[e] * (p[e] / q[e]);
+    return rare;
+}
+
+// sind / cosd pairs for |x| < 360 (longitudes in [0,360), latitudes in [-90,90]: rem(x,360) = x)
+template <int N> TPG_DEV void sincosd_b(const double (&x)[N], double (&sn)[N], double (&cs)[N])
+{
+    double h[N], l[N], S[N], C[N], r[N], d[N];
+    int ms[N], mc[N];
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        r[e] = absD(x[e]);
+        ms[e] = (int)(r[e] >= 45.0) + (int)(r[e] > 135.0) + (int)(r[e] >= 225.0) + (int)(r[e] > 315.0);
+        mc[e] = (int)(r[e] > 45.0) + (int)(r[e] >= 135.0) + (int)(r[e] > 225.0) + (int)(r[e] >= 315.0);
+        d[e] = (double)(90 * ms[e]) - r[e];
+        double t = absD(d[e]);
+        double hh = t * kDeg2Rad;
+        l[e] = fmaD(t, kDeg2Rad, -hh) + t * kDeg2RadLo;
+        h[e] = hh;
+    }
+    ksin_b<N>(h, l, S);
+    kcos_b<N>(h, l, C);
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        double sg = csign(1.0, x[e]);
+        double dsg = csign(1.0, d[e]);
+        double bs = (ms[e] & 1) ? C[e] : S[e];
+        double fs = ms[e] == 2 ? dsg * sg : (ms[e] >= 3 ? -sg : sg);
+        sn[e] = fs * bs;
+        double bc = (mc[e] & 1) ? S[e] : C[e];
+        double fc = (mc[e] & 1) ? csign(1.0, mc[e] == 1 ? 90.0 - r[e] : r[e] - 270.0) : (mc[e] == 2 ? -1.0 : 1.0);
+        cs[e] = fc * bc;
+    }
+}
+
+// exact fmod(x, 360) for |x| < 720 (select form of tpgm::fmod360)
+TPG_DEV double fmod360_small(double x)
+{
+    double ax = absD(x);
+    return ax < 360.0 ? x : csign(ax - 360.0, x);
+}
+
+}  // namespace tpgb

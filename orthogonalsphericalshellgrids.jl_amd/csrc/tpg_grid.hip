@@ -21,6 +21,7 @@
 // analytic function.
 #include "tpg_common.hpp"
 #include "tpg_math.hpp"
+#include "tpg_batch.hpp"
 #include <stdlib.h>
 
 using namespace tpgm;
@@ -415,6 +416,213 @@ __global__ __launch_bounds__(256) void k_cells_march(GridK g, OutPtrs o, MarchAr
 }
 #undef HAV
 
+// ---- K1 (fast marching form) ---------------------------------------------------------------
+// Same marching scheme as k_cells_march, restructured for FP64 issue efficiency:
+//  * rows j < Ny need no fold / substitution / pole logic, so a lane's lambda-table values
+//    (a sind, a cosd at its Face and Center column) are loop-invariant registers and the per-row
+//    psi-table values are wave-uniform; the index maps of coord() are left to the one special row;
+//  * all transcendentals of a step are evaluated by the straight-line batch forms of
+//    tpg_batch.hpp (4 independent chains per basic block), with rare cases patched afterwards;
+//  * coordinates are stored when computed, so the marching state is (lambda, a, cos a[, X, Y, Z]).
+// Bit-identical to k_cells / k_cells_march (tests/test_gpu_grid.py).
+struct Step4 {           // the 4 points a step creates: k = 0 FC(jc), 1 CC(jc), 2 FF(jf), 3 CF(jf)
+    double lam[4], phi[4], a[4], ca[4];
+    double X[2], Y[2], Z[2];     // 0: CC, 1: FF
+};
+
+struct LaneConst { double aslF, aclF, aslC, aclC, hemi; };
+
+__device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc, int jc, int jf, Step4& s)
+{
+    const double shC = g.tj[2 * g.Ny + jc - 1], chC = g.tj[3 * g.Ny + jc - 1];
+    const double shF = g.tj[0 * g.Ny + jf - 1], chF = g.tj[1 * g.Ny + jf - 1];
+    double x[4] = { lc.aslF * chC, lc.aslC * chC, lc.aslF * chF, lc.aslC * chF };          // :67
+    double y[4] = { lc.aclF * shC, lc.aclC * shC, lc.aclF * shF, lc.aclC * shF };          // :68
+    double q[4], rr[4], at1[4], at2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt(y[k] * y[k] + x[k] * x[k]); }
+    tpgb::atan_b<4>(q, at1);
+    tpgb::atan_b<4>(rr, at2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double l = -kC180Pi * at1[k];                          // :77 (no pole below row Ny)
+        s.phi[k] = 90.0 - kC360Pi * at2[k];                    // :78
+        l += lc.hemi;                                          // :82
+        l += g.fplp90;                                         // :86
+        s.lam[k] = tpgb::fmod360_small(tpgb::fmod360_small(l) + 360.0);   // :87
+        s.a[k] = s.phi[k] * kDeg2Rad;
+    }
+    if (tpgb::cos_b<4>(s.a, s.ca)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s.ca[k] = cosD(s.a[k]);
+    }
+    double ang[4] = { s.lam[1], s.phi[1], s.lam[2], s.phi[2] }, sn[4], cs[4];
+    tpgb::sincosd_b<4>(ang, sn, cs);
+    s.X[0] = cs[0] * cs[1]; s.Y[0] = sn[0] * cs[1]; s.Z[0] = sn[1];      // CC
+    s.X[1] = cs[2] * cs[3]; s.Y[1] = sn[2] * cs[3]; s.Z[1] = sn[3];      // FF
+}
+
+// general rows (row Ny: fold, substitution, pole; row 0: zero south halo) through coord()
+__device__ __noinline__ void points_general(const GridK& g, int i, int jc, int jf, Step4& s)
+{
+    Pt fc = make_pt(g, 1, 0, i, jc), cf = make_pt(g, 0, 1, i, jf);
+    PtX cc = make_ptx(g, 0, 0, i, jc), ff = make_ptx(g, 1, 1, i, jf);
+    s.lam[0] = fc.lam; s.phi[0] = fc.phi; s.a[0] = fc.a; s.ca[0] = fc.ca;
+    s.lam[1] = cc.lam; s.phi[1] = cc.phi; s.a[1] = cc.a; s.ca[1] = cc.ca;
+    s.lam[2] = ff.lam; s.phi[2] = ff.phi; s.a[2] = ff.a; s.ca[2] = ff.ca;
+    s.lam[3] = cf.lam; s.phi[3] = cf.phi; s.a[3] = cf.a; s.ca[3] = cf.ca;
+    s.X[0] = cc.X; s.Y[0] = cc.Y; s.Z[0] = cc.Z;
+    s.X[1] = ff.X; s.Y[1] = ff.Y; s.Z[1] = ff.Z;
+}
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, MarchArgs m)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int strip = wv / m.nwx;
+    const int xw = wv - strip * m.nwx;
+    const int jlo = g.jm_lo + strip * m.L;
+    if (jlo > g.jm_hi) return;
+    const int jhi = min(jlo + m.L - 1, g.jm_hi);
+    int i = xw * 62 + lane;                                        // lanes 0 / 63: west / east apron
+    const bool emit = lane >= 1 && lane <= 62 && i <= g.Nx;
+    if (i > g.Nx + 1) i = g.Nx + 1;
+    const double R = g.R;
+    const bool small_lon = absD(g.fplp90) <= 360.0;                // |l| < 720 before the wrap
+
+    LaneConst lc;
+    {
+        const int iw = i < 1 ? i + g.Nx : (i > g.Nx ? i - g.Nx : i);
+        int i0 = iw - g.shift; if (i0 < 1) i0 += g.Nx;
+        lc.aslF = g.ti[0 * g.Nx + iw - 1]; lc.aclF = g.ti[1 * g.Nx + iw - 1];
+        lc.aslC = g.ti[2 * g.Nx + iw - 1]; lc.aclC = g.ti[3 * g.Nx + iw - 1];
+        lc.hemi = (i0 <= g.Nx / 2) ? -90.0 : 90.0;
+    }
+    const long long col = (long long)(i + g.Hx - 1);
+    auto rowoff = [&](int j) -> long long { return col + (long long)g.sx * (j - g.jstart + g.Hy); };
+
+    // marching state: previous-row points (own + neighbours)
+    Nb fcP, cfP, cfWP;
+    NbX ccP, ffP, ccWP, ffEP;
+    {
+        Step4 s;
+        // prologue: FC, CC on row jlo-1; FF, CF on row jlo
+        if (jlo - 1 >= 1 && jlo - 1 < g.Ny && small_lon) points_fast(g, lc, jlo - 1, jlo, s);
+        else { Step4 tmp; points_general(g, i, jlo - 1, jlo, tmp); s = tmp; }   // only tmp is address-taken
+        if (emit) {
+            long long off = rowoff(jlo);
+            put<T, NT>(o, TPG_LAMBDA_FF, off, s.lam[2]); put<T, NT>(o, TPG_PHI_FF, off, s.phi[2]);
+            put<T, NT>(o, TPG_LAMBDA_CF, off, s.lam[3]); put<T, NT>(o, TPG_PHI_CF, off, s.phi[3]);
+        }
+        fcP = Nb{ s.lam[0], s.a[0], s.ca[0] };
+        ccP = NbX{ s.lam[1], s.a[1], s.ca[1], s.X[0], s.Y[0], s.Z[0] };
+        ffP = NbX{ s.lam[2], s.a[2], s.ca[2], s.X[1], s.Y[1], s.Z[1] };
+        cfP = Nb{ s.lam[3], s.a[3], s.ca[3] };
+        ccWP = NbX{ shf<-1>(ccP.lam), shf<-1>(ccP.a), shf<-1>(ccP.ca), shf<-1>(ccP.X), shf<-1>(ccP.Y), shf<-1>(ccP.Z) };
+        ffEP = NbX{ shf<+1>(ffP.lam), shf<+1>(ffP.a), shf<+1>(ffP.ca), shf<+1>(ffP.X), shf<+1>(ffP.Y), shf<+1>(ffP.Z) };
+        cfWP = Nb{ shf<-1>(cfP.lam), shf<-1>(cfP.a), shf<-1>(cfP.ca) };
+    }
+
+    for (int j = jlo; j <= jhi; ++j) {
+        Step4 s;
+        if (j < g.Ny && small_lon) points_fast(g, lc, j, j + 1, s);
+        else { Step4 tmp; points_general(g, i, j, j + 1, tmp); s = tmp; }
+        if (emit) {
+            long long off = rowoff(j);
+            put<T, NT>(o, TPG_LAMBDA_FC, off, s.lam[0]); put<T, NT>(o, TPG_PHI_FC, off, s.phi[0]);
+            put<T, NT>(o, TPG_LAMBDA_CC, off, s.lam[1]); put<T, NT>(o, TPG_PHI_CC, off, s.phi[1]);
+            if (j + 1 <= jhi) {
+                long long off1 = off + g.sx;
+                put<T, NT>(o, TPG_LAMBDA_FF, off1, s.lam[2]); put<T, NT>(o, TPG_PHI_FF, off1, s.phi[2]);
+                put<T, NT>(o, TPG_LAMBDA_CF, off1, s.lam[3]); put<T, NT>(o, TPG_PHI_CF, off1, s.phi[3]);
+            }
+        }
+        const Nb fc = Nb{ s.lam[0], s.a[0], s.ca[0] };
+        const NbX cc = NbX{ s.lam[1], s.a[1], s.ca[1], s.X[0], s.Y[0], s.Z[0] };
+        const NbX ff = NbX{ s.lam[2], s.a[2], s.ca[2], s.X[1], s.Y[1], s.Z[1] };
+        const Nb cf = Nb{ s.lam[3], s.a[3], s.ca[3] };
+        const Nb fcE = Nb{ shf<+1>(fc.lam), shf<+1>(fc.a), shf<+1>(fc.ca) };                                        // FC(i+1, j)
+        const NbX ccW = NbX{ shf<-1>(cc.lam), shf<-1>(cc.a), shf<-1>(cc.ca), shf<-1>(cc.X), shf<-1>(cc.Y), shf<-1>(cc.Z) };   // CC(i-1, j)
+        const NbX ffE = NbX{ shf<+1>(ff.lam), shf<+1>(ff.a), shf<+1>(ff.ca), shf<+1>(ff.X), shf<+1>(ff.Y), shf<+1>(ff.Z) };   // FF(i+1, j+1)
+        const Nb cfW = Nb{ shf<-1>(cf.lam), shf<-1>(cf.a), shf<-1>(cf.ca) };                                        // CF(i-1, j+1)
+
+        // ---- 8 haversines (x = first argument, y = second; tripolar_grid_utils.jl:13-21)
+        //      e: 0 dxcc(fcE,fc) 1 dxfc(cc,ccW) 2 dxcf(ffEP,ffP) 3 dxff(cfP,cfWP)
+        //         4 dycc(cf,cfP) 5 dyfc(ff,ffP) 6 dycf(cc,ccP)   7 dyff(fc,fcP)
+        const double xl_[8] = { fcE.lam, cc.lam, ffEP.lam, cfP.lam, cf.lam, ff.lam, cc.lam, fc.lam };
+        const double xa_[8] = { fcE.a, cc.a, ffEP.a, cfP.a, cf.a, ff.a, cc.a, fc.a };
+        const double xc_[8] = { fcE.ca, cc.ca, ffEP.ca, cfP.ca, cf.ca, ff.ca, cc.ca, fc.ca };
+        const double yl_[8] = { fc.lam, ccW.lam, ffP.lam, cfWP.lam, cfP.lam, ffP.lam, ccP.lam, fcP.lam };
+        const double ya_[8] = { fc.a, ccW.a, ffP.a, cfWP.a, cfP.a, ffP.a, ccP.a, fcP.a };
+        const double yc_[8] = { fc.ca, ccW.ca, ffP.ca, cfWP.ca, cfP.ca, ffP.ca, ccP.ca, fcP.ca };
+        double d[8];
+#pragma unroll
+        for (int hb = 0; hb < 8; hb += 4) {          // two groups of 4 independent chains
+            double hp[4], hl[4], s1[4], s2[4], rm[4], as[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double dl = (yl_[hb + e] - xl_[hb + e]) * kDeg2Rad;
+                double dp = ya_[hb + e] - xa_[hb + e];
+                hp[e] = dp / 2; hl[e] = dl / 2;
+            }
+            if (tpgb::sin_small_b<4>(hp, s1)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s1[e] = sinD(hp[e]);
+            }
+            if (tpgb::sin_small_b<4>(hl, s2)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s2[e] = sinD(hl[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double h = s1[e] * s1[e] + xc_[hb + e] * yc_[hb + e] * (s2[e] * s2[e]);
+                double r = sqrt(h);
+                rm[e] = r != r ? r : (r < 1.0 ? r : 1.0);
+            }
+            if (tpgb::asin_small_b<4>(rm, as)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) as[e] = asinD(rm[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[hb + e] = 2 * (R * as[e]);
+        }
+
+        // ---- 2 spherical quadrilaterals = 8 triangles (:23-28, :38-43)
+        const V3 qa[2] = { v3_of(ffP), v3_of(ccWP) }, qb[2] = { v3_of(ffEP), v3_of(ccP) };
+        const V3 qc[2] = { v3_of(ffE), v3_of(cc) },   qd[2] = { v3_of(ff), v3_of(ccW) };
+        double area[2];
+#pragma unroll
+        for (int qd_ = 0; qd_ < 2; ++qd_) {
+            const V3 a = qa[qd_], b = qb[qd_], c = qc[qd_], dd = qd[qd_];
+            double tt[4], at[4];
+            tt[0] = absD(dot3(a, cross3(b, c))) / (1 + dot3(a, b) + dot3(b, c) + dot3(a, c));
+            tt[1] = absD(dot3(a, cross3(b, dd))) / (1 + dot3(a, b) + dot3(b, dd) + dot3(a, dd));
+            tt[2] = absD(dot3(a, cross3(c, dd))) / (1 + dot3(a, c) + dot3(c, dd) + dot3(a, dd));
+            tt[3] = absD(dot3(b, cross3(c, dd))) / (1 + dot3(b, c) + dot3(c, dd) + dot3(b, dd));
+            tpgb::atan_b<4>(tt, at);
+            double A = 2 * at[0];
+            A += 2 * at[1];
+            A += 2 * at[2];
+            A += 2 * at[3];
+            area[qd_] = A / 2;
+        }
+        if (emit) {
+            long long off = rowoff(j);
+            put<T, NT>(o, TPG_DX_CC, off, d[0]); put<T, NT>(o, TPG_DX_FC, off, d[1]);
+            put<T, NT>(o, TPG_DX_CF, off, d[2]); put<T, NT>(o, TPG_DX_FF, off, d[3]);
+            put<T, NT>(o, TPG_DY_CC, off, d[4]); put<T, NT>(o, TPG_DY_FC, off, d[5]);
+            put<T, NT>(o, TPG_DY_CF, off, d[6]); put<T, NT>(o, TPG_DY_FF, off, d[7]);
+            put<T, NT>(o, TPG_AZ_CC, off, area[0] * (R * R));
+            put<T, NT>(o, TPG_AZ_FC, off, d[5] * d[1]);          // :34  dy_fc * dx_fc
+            put<T, NT>(o, TPG_AZ_CF, off, d[6] * d[2]);          // :35  dy_cf * dx_cf
+            put<T, NT>(o, TPG_AZ_FF, off, area[1] * (R * R));
+        }
+        fcP = fc; ccP = cc; ffP = ff; cfP = cf;
+        ccWP = ccW; ffEP = ffE; cfWP = cfW;
+    }
+}
+
 // ---- K2: halo cells of the 20 arrays ------------------------------------------------------------
 // x/y location of array q (order of enum tpg_array)
 __device__ __forceinline__ void array_loc(int q, int& xl, int& yl)
@@ -519,9 +727,9 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
 {
     dim3 grid1(((g.Nx + 255) / 256) * (g.jm_hi - g.jm_lo + 1));
     static const bool nt = getenv("TPG_BUILD_NT") ? atoi(getenv("TPG_BUILD_NT")) != 0 : true;
-    static const int variant = getenv("TPG_CELLS_VARIANT") ? atoi(getenv("TPG_CELLS_VARIANT")) : 1;
+    static const int variant = getenv("TPG_CELLS_VARIANT") ? atoi(getenv("TPG_CELLS_VARIANT")) : 2;
     static const int strip_rows = getenv("TPG_CELLS_STRIP") ? atoi(getenv("TPG_CELLS_STRIP")) : 0;
-    if (variant == 1) {
+    if (variant == 1 || variant == 2) {
         // strips sized so that the whole grid is (just under) one resident round of waves:
         // equal work per wave, no tail; short strips cost one extra point row each
         MarchArgs m;
@@ -534,7 +742,8 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
                 int dev = 0, cus = 256, blocks = 2;
                 (void)hipGetDevice(&dev);
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_cells_march<T, true>, 256, 0);
+                if (variant == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_cells_fast<T, true>, 256, 0);
+                else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_cells_march<T, true>, 256, 0);
                 if (blocks < 1) blocks = 1;
                 resident_waves = cus * blocks * 4;
             }
@@ -547,8 +756,13 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
         const int nstrips = (nrows + L - 1) / L;
         const int nwaves = nstrips * m.nwx;
         dim3 gridm((nwaves + 3) / 4);
-        if (nt) hipLaunchKernelGGL((k_cells_march<T, true>), gridm, dim3(256), 0, s, g, o, m);
-        else    hipLaunchKernelGGL((k_cells_march<T, false>), gridm, dim3(256), 0, s, g, o, m);
+        if (variant == 2) {
+            if (nt) hipLaunchKernelGGL((k_cells_fast<T, true>), gridm, dim3(256), 0, s, g, o, m);
+            else    hipLaunchKernelGGL((k_cells_fast<T, false>), gridm, dim3(256), 0, s, g, o, m);
+        } else {
+            if (nt) hipLaunchKernelGGL((k_cells_march<T, true>), gridm, dim3(256), 0, s, g, o, m);
+            else    hipLaunchKernelGGL((k_cells_march<T, false>), gridm, dim3(256), 0, s, g, o, m);
+        }
     }
     else if (nt) hipLaunchKernelGGL((k_cells<T, true>), grid1, dim3(256), 0, s, g, o);
     else         hipLaunchKernelGGL((k_cells<T, false>), grid1, dim3(256), 0, s, g, o);
