@@ -79,9 +79,10 @@ template <int N> TPG_DEV bool cos_b(const double (&a)[N], double (&out)[N])
     ksin_b<N>(y0, y1, S);
     kcos_b<N>(y0, y1, C);
     TPG_UNROLL for (int e = 0; e < N; ++e) {
-        int n = (int)fn[e];
-        double v = (n & 1) ? S[e] : C[e];
-        out[e] = ((n + 1) & 2) ? -v : v;
+        const int n = (int)fn[e];
+        const double v = (n & 1) ? S[e] : C[e];
+        const double nv = -v;
+        out[e] = ((n + 1) & 2) ? nv : v;
     }
     return rare;
 }
@@ -96,12 +97,21 @@ template <int N> TPG_DEV void atan_b(const double (&x)[N], double (&out)[N])
     TPG_UNROLL for (int e = 0; e < N; ++e) {
         double ax = absD(x[e]);
         direct[e] = ax < 0.4375;
-        bool b0 = ax < 0.6875, b1 = ax < 1.1875, b2 = ax < 2.4375;
-        double num = b0 ? 2.0 * ax - 1.0 : (b2 ? (b1 ? ax - 1.0 : ax - 1.5) : -1.0);
-        double den = b0 ? 2.0 + ax : (b1 ? ax + 1.0 : (b2 ? 1.0 + 1.5 * ax : ax));
-        hi[e] = b0 ? 0x1.dac670561bb4fp-2 : (b1 ? 0x1.921fb54442d18p-1 : (b2 ? 0x1.f730bd281f69bp-1 : kPio2Hi));
-        lo[e] = b0 ? 0x1.a2b7f222f65e2p-56 : (b1 ? 0x1.1a62633145c07p-55 : (b2 ? 0x1.007887af0cbbdp-56 : kPio2Lo));
+        const bool b0 = ax < 0.6875, b1 = ax < 1.1875, b2 = ax < 2.4375;
+        // every candidate is computed, then chosen with plain selects (arms are variables, so the
+        // compiler emits v_cndmask instead of divergent branches)
+        const double n0 = 2.0 * ax - 1.0, n1 = ax - 1.0, n2 = ax - 1.5;
+        const double d0 = 2.0 + ax, d1 = ax + 1.0, d2 = 1.0 + 1.5 * ax;
+        double num = -1.0, den = ax, h = kPio2Hi, l = kPio2Lo;
+        const double h2 = 0x1.f730bd281f69bp-1, l2 = 0x1.007887af0cbbdp-56;
+        const double h1 = 0x1.921fb54442d18p-1, l1 = 0x1.1a62633145c07p-55;
+        const double h0 = 0x1.dac670561bb4fp-2, l0 = 0x1.a2b7f222f65e2p-56;
+        num = b2 ? n2 : num; den = b2 ? d2 : den; h = b2 ? h2 : h; l = b2 ? l2 : l;
+        num = b1 ? n1 : num; den = b1 ? d1 : den; h = b1 ? h1 : h; l = b1 ? l1 : l;
+        num = b0 ? n0 : num; den = b0 ? d0 : den; h = b0 ? h0 : h; l = b0 ? l0 : l;
+        hi[e] = h; lo[e] = l;
         double q = num / den;
+        asm volatile("" : "+v"(q));          // keep the division unconditional: no branch around it
         t[e] = direct[e] ? ax : q;
     }
     {
@@ -120,8 +130,9 @@ template <int N> TPG_DEV void atan_b(const double (&x)[N], double (&out)[N])
         TPG_UNROLL for (int e = 0; e < N; ++e) s[e] = z[e] * s1[e] + s2[e];
     }
     TPG_UNROLL for (int e = 0; e < N; ++e) {
-        double ts = t[e] * s[e];
-        double r = direct[e] ? t[e] - ts : hi[e] - ((ts - lo[e]) - t[e]);
+        const double ts = t[e] * s[e];
+        const double rd = t[e] - ts, rg = hi[e] - ((ts - lo[e]) - t[e]);
+        const double r = direct[e] ? rd : rg;
         out[e] = csign(r, x[e]);
     }
 }
@@ -166,13 +177,20 @@ template <int N> TPG_DEV void sincosd_b(const double (&x)[N], double (&sn)[N], d
     ksin_b<N>(h, l, S);
     kcos_b<N>(h, l, C);
     TPG_UNROLL for (int e = 0; e < N; ++e) {
-        double sg = csign(1.0, x[e]);
-        double dsg = csign(1.0, d[e]);
-        double bs = (ms[e] & 1) ? C[e] : S[e];
-        double fs = ms[e] == 2 ? dsg * sg : (ms[e] >= 3 ? -sg : sg);
+        const double sg = csign(1.0, x[e]), nsg = -sg;
+        const double dsg = csign(1.0, d[e]);
+        const double bs = (ms[e] & 1) ? C[e] : S[e];
+        const double f2 = dsg * sg;
+        double fs = sg;
+        fs = ms[e] >= 3 ? nsg : fs;
+        fs = ms[e] == 2 ? f2 : fs;
         sn[e] = fs * bs;
-        double bc = (mc[e] & 1) ? S[e] : C[e];
-        double fc = (mc[e] & 1) ? csign(1.0, mc[e] == 1 ? 90.0 - r[e] : r[e] - 270.0) : (mc[e] == 2 ? -1.0 : 1.0);
+        const double bc = (mc[e] & 1) ? S[e] : C[e];
+        const double a1 = 90.0 - r[e], a3 = r[e] - 270.0;
+        const double arg = mc[e] == 1 ? a1 : a3;
+        const double fodd = csign(1.0, arg);
+        const double feven = mc[e] == 2 ? -1.0 : 1.0;
+        const double fc = (mc[e] & 1) ? fodd : feven;
         cs[e] = fc * bc;
     }
 }
@@ -180,8 +198,9 @@ template <int N> TPG_DEV void sincosd_b(const double (&x)[N], double (&sn)[N], d
 // exact fmod(x, 360) for |x| < 720 (select form of tpgm::fmod360)
 TPG_DEV double fmod360_small(double x)
 {
-    double ax = absD(x);
-    return ax < 360.0 ? x : csign(ax - 360.0, x);
+    const double ax = absD(x);
+    const double w = csign(ax - 360.0, x);
+    return ax < 360.0 ? x : w;
 }
 
 }  // namespace tpgb

@@ -577,8 +577,9 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 double h = s1[e] * s1[e] + xc_[hb + e] * yc_[hb + e] * (s2[e] * s2[e]);
-                double r = sqrt(h);
-                rm[e] = r != r ? r : (r < 1.0 ? r : 1.0);
+                const double r = sqrt(h);
+                const double mn = r < 1.0 ? r : 1.0;
+                rm[e] = r != r ? r : mn;
             }
             if (tpgb::asin_small_b<4>(rm, as)) {
 #pragma unroll
