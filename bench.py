@@ -99,17 +99,26 @@ def main():
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    rehearse = os.environ.get("TPG_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # Rehearsal mode for a 1-GPU box (never used by the driver): TPG_BENCH_REHEARSE=1 runs the N-rank
+    # code path with every rank on cuda:0 and the seam messages staged through host memory over gloo
+    # (RCCL refuses two ranks on one device).  Timings of such a run are meaningless.
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lib = _lib.lib()
     halo = (H, H, H)
     gsize = (NX, NY * world, NZ)                                   # weak scaling: 1800 rows per rank
     if world > 1:
-        arch = osg.Distributed(osg.GPU(local_rank), osg.Partition(y=world), local_rank=rank)
+        arch = osg.Distributed(osg.GPU(0 if rehearse else local_rank), osg.Partition(y=world), local_rank=rank)
         jstart, jend = osg.local_row_range(gsize[1], arch)
     else:
         arch, jstart, jend = osg.GPU(local_rank), 1, NY
@@ -140,6 +149,15 @@ def main():
     stream = _lib.current_stream_ptr(dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
+    transport = None
+    if rehearse and world > 1:
+        def transport(plan, send, recv, group):                     # host-staged stand-in for RCCL p2p
+            hs = {k: v.cpu() for k, v in send.items()}
+            hr = {k: torch.empty_like(v) for k, v in hs.items()}
+            osg.torch_distributed_transport(plan, hs, hr, group)
+            for k in recv:
+                recv[k].copy_(hr[k])
+
     def step(marks=None):
         if marks is not None: marks[0].record()
         _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
@@ -149,10 +167,11 @@ def main():
         if marks is not None: marks[2].record()
         _lib.check(lib.tpg_periodic_x_fill(fptrs, n, *geom, _lib.TPG_F64, stream))
         if world > 1:
-            exchange_y_halos(band_fields, arch)
+            exchange_y_halos(band_fields, arch, transport=transport)
         if marks is not None: marks[3].record()
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -167,12 +186,17 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=None if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)      # ms
     t_build, t_zip, t_rest = avg(0, 1), avg(1, 2), avg(2, 3)
+    if world > 1:
+        # the zipper runs on the north (last) rank only: ship its launch time to rank 0 for the report
+        tz = torch.tensor([t_zip], dtype=torch.float64, device=None if rehearse else dev)
+        dist.broadcast(tz, src=world - 1)
+        t_zip = float(tz.item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -192,21 +216,21 @@ def main():
                        "parallelism": f"latitude-bands x{world}"},
             "precompute_cells_per_s": NX * NY / (t_build * 1e-3),
             "precompute_ms": t_build, "zipper_ms": t_zip, "periodic_and_exchange_ms": t_rest,
-            "zipper_GBps": zbytes / (t_zip * 1e-3) / 1e9 if north_rank else None,
+            "zipper_GBps": zbytes / (t_zip * 1e-3) / 1e9,
         }
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("k_zipper_cols_bytes_per_launch")
-        if north_rank:
-            line["roofline"] = {"kernel": "k_zipper_cols<double,2,4> (4 fields x 75 levels, one launch)", "bound": "hbm",
+        if True:
+            line["roofline"] = {"kernel": "k_zipper_cols<double,2,4> (4 fields x 75 levels, one launch" + (", on the north rank" if world > 1 else "") + ")", "bound": "hbm",
                                 "achieved": zbytes / (t_zip * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": zbytes / (t_zip * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                                 "algorithmic_bytes_per_launch": zbytes, "launch_ms": t_zip}
         flops = 3500.0 * NX * NY                                    # ~3.5 kflop FP64 per cell
         line["roofline_precompute"] = {
-            "kernel": "tpg_build_grid (k_tables + k_cells_march + k_halos + k_south)", "bound": "hbm",
+            "kernel": "tpg_build_grid (k_tables + k_cells_fast + k_halos + k_south)", "bound": "hbm",
             "achieved": 160.0 * band_cells / (t_build * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
             "algorithmic_bytes_per_launch": 160 * band_cells,

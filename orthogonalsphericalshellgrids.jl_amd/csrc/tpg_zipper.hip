@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void k_zipper_cols(FieldTable ft, ZipArgs a)
     vec_t vf = {}, old = {};
     if (fix) {
         vf = *reinterpret_cast<const lvec_t*>(lvl + sx * prow_ny + soff);
-        old = *reinterpret_cast<const vec_t*>(lvl + sx * prow_ny + (i - 1));
+        if (i <= a.Nx / 2)       // only the chunk that straddles Nx/2 keeps part of the old row
+            old = *reinterpret_cast<const vec_t*>(lvl + sx * prow_ny + (i - 1));
     }
     const T s = (T)sgn, as = (T)(sgn < 0 ? -sgn : sgn);
 #pragma unroll
@@ -232,6 +233,25 @@ __global__ __launch_bounds__(256) void k_periodic_x(PtrTable pt, PerArgs a)
     T* c = static_cast<T*>(pt.ptr[f]) + row * a.sx;
     c[h] = c[a.Nx + h];
     c[a.Hx + a.Nx + h] = c[a.Hx + h];
+}
+
+// 16-byte form (Hx and Nx multiples of the 16-B element count, 16-B aligned fields): one thread
+// moves one 16-B chunk of the west halo and one of the east halo of a row; grid.y = field.
+template <typename V>
+__global__ __launch_bounds__(256) void k_periodic_x_vec(PtrTable pt, PerArgs a, int cpr /* chunks per side */, int epc /* elems per chunk */)
+{
+    long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= a.nrows * cpr) return;
+    long long row = item / cpr;
+    int v = (int)(item - row * cpr);
+    char* base = static_cast<char*>(pt.ptr[blockIdx.y]);
+    const size_t esz = 16 / epc;
+    V* c = reinterpret_cast<V*>(base + (size_t)row * a.sx * esz);
+    const int nxc = a.Nx / epc, hxc = a.Hx / epc;
+    V w = c[nxc + v];            // interior column Nx-Hx+1.. (chunk units: Hx + Nx - Hx = Nx elements in)
+    V e = c[hxc + v];            // interior column 1..
+    c[v] = w;
+    c[hxc + nxc + v] = e;
 }
 
 // ---- latitude-band message pack / unpack --------------------------------------------------------
@@ -400,10 +420,20 @@ int tpg_periodic_x_fill(void* const fields[], int nfields, int Nx, int Ny, int N
         PtrTable pt;
         for (int f = 0; f < n; ++f) pt.ptr[f] = fields[f0 + f];
         PerArgs a{ Nx, Hx, g.sx, (long long)g.sy * (Nz + 2 * Hz), n };
-        long long total = a.nrows * Hx * n;
-        dim3 grid((unsigned)((total + 255) / 256));
-        if (ft == TPG_F64) hipLaunchKernelGGL(k_periodic_x<double>, grid, dim3(256), 0, s, pt, a);
-        else               hipLaunchKernelGGL(k_periodic_x<float>, grid, dim3(256), 0, s, pt, a);
+        const int epc = ft == TPG_F64 ? 2 : 4;
+        bool vec = (Hx % epc == 0) && (Nx % epc == 0);
+        for (int f = 0; f < n && vec; ++f) vec = ((uintptr_t)pt.ptr[f] % 16) == 0;
+        if (vec) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const int cpr = Hx / epc;
+            dim3 gridv((unsigned)((a.nrows * cpr + 255) / 256), (unsigned)n);
+            hipLaunchKernelGGL(k_periodic_x_vec<u32x4>, gridv, dim3(256), 0, s, pt, a, cpr, epc);
+        } else {
+            long long total = a.nrows * Hx * n;
+            dim3 grid((unsigned)((total + 255) / 256));
+            if (ft == TPG_F64) hipLaunchKernelGGL(k_periodic_x<double>, grid, dim3(256), 0, s, pt, a);
+            else               hipLaunchKernelGGL(k_periodic_x<float>, grid, dim3(256), 0, s, pt, a);
+        }
         if ((rc = tpg::launch_status("k_periodic_x"))) return rc;
     }
     return TPG_OK;
