@@ -324,12 +324,17 @@ void launch_cols(int Hy, dim3 grid, hipStream_t s, const FieldTable& ft, const Z
     }
 }
 
-// tuning knob (tools/zipper_tune.py): TPG_ZIPPER_VARIANT = 0 row items, 1 columns, 2 columns + nontemporal
-// loads and stores, 3 nontemporal loads only, 4 nontemporal stores only
+// TPG_ZIPPER_VARIANT (tools/zipper_tune.sh): 0 row items, 1 columns, 2 columns + nontemporal loads and
+// stores, 3 columns + nontemporal loads (DEFAULT), 4 columns + nontemporal stores.
+// Measured at config 3 (device timestamps, us): warm / cold-clean / cold-dirty caches
+//   1: 12.9 / 15.9 / 24.0     3: 14.9 / 16.0 / 18.2     in bench.py (after the grid build): 15.0 vs 14.7.
+// The fold's sources are not reused soon, so streaming loads cost nothing in a real step and make the
+// kernel robust against a predecessor that left the caches dirty; 512/1024-thread blocks and two
+// levels per thread were measured too and are 3-15 % slower.
 int zipper_variant()
 {
     const char* e = getenv("TPG_ZIPPER_VARIANT");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 3;
 }
 
 template <typename T, int W>
