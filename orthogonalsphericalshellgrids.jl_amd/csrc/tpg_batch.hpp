@@ -76,8 +76,12 @@ template <int N> TPG_DEV bool cos_b(const double (&a)[N], double (&out)[N])
         y1[e] = (r - y0[e]) - w;
         rare |= (expo(a[e]) - expo(y0[e]) > 16);
     }
-    ksin_b<N>(y0, y1, S);
-    kcos_b<N>(y0, y1, C);
+    // lanes of a wave sit on neighbouring latitudes: usually every argument needs the same kernel
+    bool odd = false, even = false;
+    TPG_UNROLL for (int e = 0; e < N; ++e) { const int n = (int)fn[e]; odd |= (n & 1) != 0; even |= (n & 1) == 0; }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { S[e] = 0.0; C[e] = 0.0; }
+    if (__any(odd)) ksin_b<N>(y0, y1, S);
+    if (__any(even)) kcos_b<N>(y0, y1, C);
     TPG_UNROLL for (int e = 0; e < N; ++e) {
         const int n = (int)fn[e];
         const double v = (n & 1) ? S[e] : C[e];
@@ -135,6 +139,92 @@ template <int N> TPG_DEV void atan_b(const double (&x)[N], double (&out)[N])
         const double r = direct[e] ? rd : rg;
         out[e] = csign(r, x[e]);
     }
+}
+
+// Range-reduction constants of atan_b, one row per msun interval id = 0..3:
+//   t = (p*ax - q) / (r + s*ax),  result = hi - ((t*poly - lo) - t)
+// (p*ax, s*ax are exact for p,s in {0,1,2}; 1.5*ax rounds exactly as the scalar code's 1.5*ax).
+// Looked up per lane from LDS (3 ds_read_b128) instead of 24 v_cndmask + the unused candidates.
+struct AtanRow { double p, q, r, s, hi, lo; };
+#define TPG_ATAN_TABLE_DOUBLES 24
+TPG_DEV void atan_table_init(double* tab, int tid)
+{
+    const double rows[4][6] = {
+        { 2.0, 1.0, 2.0, 1.0, 0x1.dac670561bb4fp-2, 0x1.a2b7f222f65e2p-56 },     // [0.4375, 0.6875): (2x-1)/(2+x), atan(0.5)
+        { 1.0, 1.0, 1.0, 1.0, 0x1.921fb54442d18p-1, 0x1.1a62633145c07p-55 },     // [0.6875, 1.1875): (x-1)/(x+1),  atan(1)
+        { 1.0, 1.5, 1.0, 1.5, 0x1.f730bd281f69bp-1, 0x1.007887af0cbbdp-56 },     // [1.1875, 2.4375): (x-1.5)/(1+1.5x), atan(1.5)
+        { 0.0, 1.0, 0.0, 1.0, kPio2Hi, kPio2Lo } };                              // [2.4375, inf]:   -1/x, pi/2
+    if (tid < TPG_ATAN_TABLE_DOUBLES) tab[tid] = rows[tid / 6][tid % 6];
+}
+
+// atan(x), all x, with the interval constants taken from the LDS table (see atan_b for the
+// value-equivalence of dropping the msun early-outs).  p = 0 on the last interval: the numerator
+// uses min(ax, 2^1000) so that an infinite argument (y/x at x = +-0) still gives 0*ax - 1 = -1.
+template <int N> TPG_DEV void atan_tab_b(const double (&x)[N], double (&out)[N], const double* tab)
+{
+    double t[N], hi[N], lo[N], s[N], ax[N];
+    bool direct[N];
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        ax[e] = absD(x[e]);
+        direct[e] = ax[e] < 0.4375;
+        const int id = (int)(ax[e] >= 0.6875) + (int)(ax[e] >= 1.1875) + (int)(ax[e] >= 2.4375);
+        const AtanRow row = *reinterpret_cast<const AtanRow*>(tab + 6 * id);
+        hi[e] = row.hi; lo[e] = row.lo;
+        const double axn = ax[e] < 0x1p1000 ? ax[e] : 0x1p1000;
+        const double num = row.p * axn - row.q;
+        const double den = row.r + row.s * ax[e];
+        double q = num / den;
+        asm volatile("" : "+v"(q));
+        t[e] = direct[e] ? ax[e] : q;
+    }
+    {
+        double z[N], w[N], s1[N], s2[N];
+        TPG_UNROLL for (int e = 0; e < N; ++e) { z[e] = t[e] * t[e]; w[e] = z[e] * z[e]; }
+        TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], 1.62858201153657823623e-02, 4.97687799461593236017e-02);
+                                                 s2[e] = fmaD(w[e], -3.65315727442169155270e-02, -5.83357013379057348645e-02); }
+        TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 6.66107313738753120669e-02);
+                                                 s2[e] = fmaD(w[e], s2[e], -7.69187620504482999495e-02); }
+        TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 9.09088713343650656196e-02);
+                                                 s2[e] = fmaD(w[e], s2[e], -1.11111104054623557880e-01); }
+        TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 1.42857142725034663711e-01);
+                                                 s2[e] = fmaD(w[e], s2[e], -1.99999999998764832476e-01); }
+        TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 3.33333333333329318027e-01);
+                                                 s2[e] = w[e] * s2[e]; }
+        TPG_UNROLL for (int e = 0; e < N; ++e) s[e] = z[e] * s1[e] + s2[e];
+    }
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        const double ts = t[e] * s[e];
+        const double rd = t[e] - ts, rg = hi[e] - ((ts - lo[e]) - t[e]);
+        const double r = direct[e] ? rd : rg;
+        out[e] = csign(r, x[e]);
+    }
+}
+
+// atan(x) for |x| < 0.4375: the msun "direct" branch only (no argument reduction, no division).
+// The eight spherical-triangle tangents of a cell are O(cell area) ~ 1e-6, so this is their path.
+// rare: some |x| >= 0.4375 (or NaN) -> caller uses atan_b.
+template <int N> TPG_DEV bool atan_small_b(const double (&x)[N], double (&out)[N])
+{
+    double t[N], z[N], w[N], s1[N], s2[N];
+    bool rare = false;
+    TPG_UNROLL for (int e = 0; e < N; ++e) { t[e] = absD(x[e]); rare |= !(t[e] < 0.4375); }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { z[e] = t[e] * t[e]; w[e] = z[e] * z[e]; }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], 1.62858201153657823623e-02, 4.97687799461593236017e-02);
+                                             s2[e] = fmaD(w[e], -3.65315727442169155270e-02, -5.83357013379057348645e-02); }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 6.66107313738753120669e-02);
+                                             s2[e] = fmaD(w[e], s2[e], -7.69187620504482999495e-02); }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 9.09088713343650656196e-02);
+                                             s2[e] = fmaD(w[e], s2[e], -1.11111104054623557880e-01); }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 1.42857142725034663711e-01);
+                                             s2[e] = fmaD(w[e], s2[e], -1.99999999998764832476e-01); }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { s1[e] = fmaD(w[e], s1[e], 3.33333333333329318027e-01);
+                                             s2[e] = w[e] * s2[e]; }
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        const double sm = z[e] * s1[e] + s2[e];
+        const double r = t[e] - t[e] * sm;
+        out[e] = csign(r, x[e]);
+    }
+    return rare;
 }
 
 // asin(x) for |x| < 0.5.  tpgm::asinD returns x for |x| < 2^-26: x + x (p/q) with p/q ~ x^2/6

@@ -432,7 +432,7 @@ struct Step4 {           // the 4 points a step creates: k = 0 FC(jc), 1 CC(jc),
 
 struct LaneConst { double aslF, aclF, aslC, aclC, hemi; };
 
-__device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc, int jc, int jf, Step4& s)
+__device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc, int jc, int jf, Step4& s, const double* atab)
 {
     const double shC = g.tj[2 * g.Ny + jc - 1], chC = g.tj[3 * g.Ny + jc - 1];
     const double shF = g.tj[0 * g.Ny + jf - 1], chF = g.tj[1 * g.Ny + jf - 1];
@@ -441,8 +441,8 @@ __device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc,
     double q[4], rr[4], at1[4], at2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt(y[k] * y[k] + x[k] * x[k]); }
-    tpgb::atan_b<4>(q, at1);
-    tpgb::atan_b<4>(rr, at2);
+    tpgb::atan_tab_b<4>(q, at1, atab);
+    tpgb::atan_tab_b<4>(rr, at2, atab);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         double l = -kC180Pi * at1[k];                          // :77 (no pole below row Ny)
@@ -478,6 +478,9 @@ __device__ __noinline__ void points_general(const GridK& g, int i, int jc, int j
 template <typename T, bool NT>
 __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, MarchArgs m)
 {
+    __shared__ __attribute__((aligned(16))) double atab[TPG_ATAN_TABLE_DOUBLES];
+    tpgb::atan_table_init(atab, threadIdx.x);
+    __syncthreads();                                               // the only barrier: before any wave can exit
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int strip = wv / m.nwx;
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
     {
         Step4 s;
         // prologue: FC, CC on row jlo-1; FF, CF on row jlo
-        if (jlo - 1 >= 1 && jlo - 1 < g.Ny && small_lon) points_fast(g, lc, jlo - 1, jlo, s);
+        if (jlo - 1 >= 1 && jlo - 1 < g.Ny && small_lon) points_fast(g, lc, jlo - 1, jlo, s, atab);
         else { Step4 tmp; points_general(g, i, jlo - 1, jlo, tmp); s = tmp; }   // only tmp is address-taken
         if (emit) {
             long long off = rowoff(jlo);
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
 
     for (int j = jlo; j <= jhi; ++j) {
         Step4 s;
-        if (j < g.Ny && small_lon) points_fast(g, lc, j, j + 1, s);
+        if (j < g.Ny && small_lon) points_fast(g, lc, j, j + 1, s, atab);
         else { Step4 tmp; points_general(g, i, j, j + 1, tmp); s = tmp; }
         if (emit) {
             long long off = rowoff(j);
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
             tt[1] = absD(dot3(a, cross3(b, dd))) / (1 + dot3(a, b) + dot3(b, dd) + dot3(a, dd));
             tt[2] = absD(dot3(a, cross3(c, dd))) / (1 + dot3(a, c) + dot3(c, dd) + dot3(a, dd));
             tt[3] = absD(dot3(b, cross3(c, dd))) / (1 + dot3(b, c) + dot3(c, dd) + dot3(b, dd));
-            tpgb::atan_b<4>(tt, at);
+            if (__any(tpgb::atan_small_b<4>(tt, at))) tpgb::atan_b<4>(tt, at);   // wave-uniform fallback
             double A = 2 * at[0];
             A += 2 * at[1];
             A += 2 * at[2];
