@@ -111,6 +111,19 @@ int tpg_zipper_fill(void *const fields[], int nfields,
                     int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
                     int kstart, int kcount, int ft, void *stream);
 
+/* Same call, with the kernel's own start / stop device timestamps recorded into two HIP events
+ * (hipExtLaunchKernelGGL): what bench.py uses for roofline.achieved, so that the live number is the
+ * kernel duration rocprofv3 reports, free of stream-marker and launch-boundary overhead.
+ * nfields <= TPG_MAX_FIELDS (one kernel).  Events: tpg_event_create / hipEventCreate. */
+int tpg_zipper_fill_timed(void *const fields[], int nfields,
+                          const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                          int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
+                          int kstart, int kcount, int ft, void *stream,
+                          void *start_event, void *stop_event);
+int tpg_event_create(void **event);
+int tpg_event_destroy(void *event);
+int tpg_event_elapsed_ms(void *start_event, void *stop_event, float *ms); /* waits for stop_event */
+
 /* Oceananigans' periodic west/east halo fill, which fill_halo_regions! runs AFTER the zipper
  * (pinned by test/test_zipper_boundary_conditions.jl:42-45): every row and level of the parent. */
 int tpg_periodic_x_fill(void *const fields[], int nfields,

@@ -58,6 +58,11 @@ SIGNATURES = {
     "tpg_build_grid": (_i, [C.POINTER(TpgParams), C.POINTER(_vp), _vp, _sz, _vp]),
     "tpg_zipper_fill": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
                         + _geom + [_i, _i, _i, _vp]),
+    "tpg_zipper_fill_timed": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
+                              + _geom + [_i, _i, _i, _vp, _vp, _vp]),
+    "tpg_event_create": (_i, [C.POINTER(_vp)]),
+    "tpg_event_destroy": (_i, [_vp]),
+    "tpg_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "tpg_periodic_x_fill": (_i, [C.POINTER(_vp), _i] + _geom + [_i, _vp]),
     "tpg_fill_halo_regions": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
                               + _geom + [_i, _i, _vp]),

@@ -18,6 +18,7 @@
 // Geometries whose rows are not 16-B chunkable (odd Hx for f64, Hx or Nx not multiple of 4 for
 // f32, misaligned base pointers) run the scalar kernel (one element per item).
 #include "tpg_common.hpp"
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 namespace {
@@ -309,18 +310,29 @@ int check_fields(void* const fields[], int nfields)
     return TPG_OK;
 }
 
+// optional per-launch device timestamps (hipExtLaunchKernelGGL start/stop events): set by
+// tpg_zipper_fill_timed for the duration of one call
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+#define TPG_LAUNCH(kernel, grid, block, stream, ...)                                                      \
+    do {                                                                                                  \
+        if (g_ev_start || g_ev_stop)                                                                      \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, g_ev_start, g_ev_stop, 0, __VA_ARGS__); \
+        else                                                                                              \
+            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                              \
+    } while (0)
+
 template <typename T, int W, bool NTL, bool NTS>
 void launch_cols(int Hy, dim3 grid, hipStream_t s, const FieldTable& ft, const ZipArgs& a)
 {
     switch (Hy) {
-    case 1: hipLaunchKernelGGL((k_zipper_cols<T, W, 1, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
-    case 2: hipLaunchKernelGGL((k_zipper_cols<T, W, 2, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
-    case 3: hipLaunchKernelGGL((k_zipper_cols<T, W, 3, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
-    case 4: hipLaunchKernelGGL((k_zipper_cols<T, W, 4, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
-    case 5: hipLaunchKernelGGL((k_zipper_cols<T, W, 5, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
-    case 6: hipLaunchKernelGGL((k_zipper_cols<T, W, 6, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
-    case 7: hipLaunchKernelGGL((k_zipper_cols<T, W, 7, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
-    default: hipLaunchKernelGGL((k_zipper_cols<T, W, 8, NTL, NTS>), grid, dim3(256), 0, s, ft, a); break;
+    case 1: TPG_LAUNCH((k_zipper_cols<T, W, 1, NTL, NTS>), grid, dim3(256), s, ft, a); break;
+    case 2: TPG_LAUNCH((k_zipper_cols<T, W, 2, NTL, NTS>), grid, dim3(256), s, ft, a); break;
+    case 3: TPG_LAUNCH((k_zipper_cols<T, W, 3, NTL, NTS>), grid, dim3(256), s, ft, a); break;
+    case 4: TPG_LAUNCH((k_zipper_cols<T, W, 4, NTL, NTS>), grid, dim3(256), s, ft, a); break;
+    case 5: TPG_LAUNCH((k_zipper_cols<T, W, 5, NTL, NTS>), grid, dim3(256), s, ft, a); break;
+    case 6: TPG_LAUNCH((k_zipper_cols<T, W, 6, NTL, NTS>), grid, dim3(256), s, ft, a); break;
+    case 7: TPG_LAUNCH((k_zipper_cols<T, W, 7, NTL, NTS>), grid, dim3(256), s, ft, a); break;
+    default: TPG_LAUNCH((k_zipper_cols<T, W, 8, NTL, NTS>), grid, dim3(256), s, ft, a); break;
     }
 }
 
@@ -372,8 +384,8 @@ int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t 
         else if (variant == 4) launch_cols<T, W, false, true>(g.Hy, grid2, s, ft, a);
         else                   launch_cols<T, W, false, false>(g.Hy, grid2, s, ft, a);
     }
-    else if (vec) hipLaunchKernelGGL((k_zipper_vec<T, W>), grid, dim3(256), 0, s, ft, a);
-    else          hipLaunchKernelGGL((k_zipper_scalar<T>), grid, dim3(256), 0, s, ft, a);
+    else if (vec) TPG_LAUNCH((k_zipper_vec<T, W>), grid, dim3(256), s, ft, a);
+    else          TPG_LAUNCH((k_zipper_scalar<T>), grid, dim3(256), s, ft, a);
     return tpg::launch_status("k_zipper");
 }
 
@@ -409,6 +421,40 @@ int tpg_zipper_fill(void* const fields[], int nfields, const int8_t xloc[], cons
         if (rc) return rc;
     }
     return TPG_OK;
+}
+
+int tpg_zipper_fill_timed(void* const fields[], int nfields, const int8_t xloc[], const int8_t yloc[],
+                          const int32_t sign[], int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
+                          int kstart, int kcount, int ft, void* stream, void* start_event, void* stop_event)
+{
+    if (nfields > TPG_MAX_FIELDS) { tpg::set_error("timed launch: at most %d fields (one kernel)", TPG_MAX_FIELDS); return TPG_ERR_UNSUPPORTED; }
+    g_ev_start = static_cast<hipEvent_t>(start_event);
+    g_ev_stop = static_cast<hipEvent_t>(stop_event);
+    int rc = tpg_zipper_fill(fields, nfields, xloc, yloc, sign, Nx, Ny, Nz, Hx, Hy, Hz, kstart, kcount, ft, stream);
+    g_ev_start = g_ev_stop = nullptr;
+    return rc;
+}
+
+int tpg_event_create(void** event)
+{
+    if (!event) { tpg::set_error("null event pointer"); return TPG_ERR_INVALID_ARGUMENT; }
+    hipEvent_t e;
+    int rc = tpg::hip_status(hipEventCreate(&e), "hipEventCreate");
+    *event = rc ? nullptr : e;
+    return rc;
+}
+
+int tpg_event_destroy(void* event)
+{
+    return event ? tpg::hip_status(hipEventDestroy(static_cast<hipEvent_t>(event)), "hipEventDestroy") : TPG_OK;
+}
+
+int tpg_event_elapsed_ms(void* start_event, void* stop_event, float* ms)
+{
+    if (!start_event || !stop_event || !ms) { tpg::set_error("null event"); return TPG_ERR_INVALID_ARGUMENT; }
+    int rc = tpg::hip_status(hipEventSynchronize(static_cast<hipEvent_t>(stop_event)), "hipEventSynchronize");
+    if (rc) return rc;
+    return tpg::hip_status(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event)), "hipEventElapsedTime");
 }
 
 int tpg_periodic_x_fill(void* const fields[], int nfields, int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
