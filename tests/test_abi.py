@@ -80,6 +80,14 @@ def test_product_has_no_cpu_path(osg):
         osg.TripolarGrid(osg.CPU(), size=(60, 30, 1))
 
 
+def test_missing_extension_fails_loudly(osg, monkeypatch, tmp_path):
+    """no silent fallback: without libtripolar_hip.so the binding raises"""
+    monkeypatch.setattr(osg._lib, "_lib", None)
+    monkeypatch.setattr(osg._lib, "LIB_PATH", str(tmp_path / "libtripolar_hip.so"))
+    with pytest.raises(ImportError, match="only backend"):
+        osg._lib.lib()
+
+
 def test_product_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd")
     for dirpath, _, files in os.walk(pkg):

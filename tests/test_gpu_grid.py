@@ -35,6 +35,9 @@ CASES = [
     dict(size=(64, 33, 1), halo=(1, 1, 1), southernmost_latitude=-75.5, radius=1.0),   # non-integer south: dd range path
     dict(size=(128, 64, 1), halo=(7, 5, 2), north_poles_latitude=60, first_pole_longitude=-35.25),
     dict(size=(8, 4, 1), halo=(4, 4, 1)),                                              # Ny == Hy: fold reaches the zero south halo
+    dict(size=(126, 40, 1), first_pole_longitude=1000.5),                              # |fpl+90| > 360: every step takes the general (coord) path
+    dict(size=(62, 24, 1), halo=(2, 2, 1)),                                            # exactly one 62-column wave window
+    dict(size=(250, 36, 1), north_poles_latitude=80.25, southernmost_latitude=-89),    # points within 1 degree of the south pole / poles near 90
 ]
 
 
@@ -83,6 +86,16 @@ def test_tenth_degree_full_parity_and_properties(osg, oracle, gpu):
         assert torch.equal(a[:, :4], a[:, Nx:Nx + 4]) and torch.equal(a[:, Nx + 4:], a[:, 4:8])
     assert osg.x_domain(grid) == (0, 360)
     assert osg.y_domain(grid) == (float(ref["phi_ff"].min()), 90)
+
+
+def test_twentyfourth_degree_parity(osg, oracle, gpu):
+    """1/24 degree (8640x4320, BASELINE config 5's grid): 37 M cells, 6 GB of Float64 arrays"""
+    size = (8640, 4320, 1)
+    grid = osg.TripolarGrid(osg.GPU(0), size=size)
+    oracle.set_threads(min(16, oracle.max_threads()))
+    ref = oracle.build_grid(size)
+    oracle.set_threads(1)
+    assert compare(grid, ref) == 0
 
 
 def test_reference_readme_numbers_on_gpu(osg, gpu, kats):
