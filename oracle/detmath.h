@@ -323,13 +323,23 @@ DM_INLINE dm_dd dm_dd_expm1_reduced(dm_dd a, int *kout)
     double kf = rint(a.hi / DM_LN2_HI);
     dm_dd r = dm_dd_sub(a, dm_dd_mul_d(ln2, kf));
     r.hi *= 0x1p-9; r.lo *= 0x1p-9;                      /* r / 512, exact */
-    /* Taylor: s = r + r^2/2! + ... + r^11/11!  (|r| < 7e-4 -> truncation < 1e-40) */
-    dm_dd term = r, s = r;
-    for (int n = 2; n <= 11; ++n) {
-        term = dm_dd_mul(term, r);
-        term = dm_dd_div(term, dm_dd_make((double)n, 0.0));
-        s = dm_dd_add(s, term);
-    }
+    /* Taylor to r^11/11! (|r| < 7e-4 -> truncation < 1e-40), Horner in double-double with the
+     * inverse factorials as dd constants (gen_constants.py): s = r + r^2 (1/2! + r (1/3! + ...)) */
+    static const dm_dd invfact[10] = {
+    { 0x1.0000000000000p-1, 0x0.0p+0 },                /* 1/2!  */
+    { 0x1.5555555555555p-3, 0x1.5555555555555p-57 },   /* 1/3!  */
+    { 0x1.5555555555555p-5, 0x1.5555555555555p-59 },   /* 1/4!  */
+    { 0x1.1111111111111p-7, 0x1.1111111111111p-63 },   /* 1/5!  */
+    { 0x1.6c16c16c16c17p-10, -0x1.f49f49f49f49fp-65 }, /* 1/6!  */
+    { 0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-73 },  /* 1/7!  */
+    { 0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76 },  /* 1/8!  */
+    { 0x1.71de3a556c734p-19, -0x1.c154f8ddc6c00p-73 }, /* 1/9!  */
+    { 0x1.27e4fb7789f5cp-22, 0x1.cbbc05b4fa99ap-76 },  /* 1/10! */
+    { 0x1.ae64567f544e4p-26, -0x1.c062e06d1f209p-80 }, /* 1/11! */
+    };
+    dm_dd pl = invfact[9];
+    for (int n = 8; n >= 0; --n) pl = dm_dd_add(invfact[n], dm_dd_mul(r, pl));
+    dm_dd s = dm_dd_add(r, dm_dd_mul(dm_dd_mul(r, r), pl));
     for (int i = 0; i < 9; ++i)                          /* (1+s)^2 - 1 = 2s + s^2 */
         s = dm_dd_add(dm_dd_mul_d(s, 2.0), dm_dd_mul(s, s));
     *kout = (int)kf;
@@ -344,7 +354,8 @@ DM_INLINE dm_dd dm_dd_exp(dm_dd a)
     e.hi *= sc; e.lo *= sc;
     return e;
 }
-/* log(a), a > 0: deterministic seed (atanh series in double), then 3 Newton steps in dd */
+/* log(a), a > 0: deterministic seed (atanh series in double, |error| < 5e-13), then 2 Newton steps
+ * in dd (error -> ~1e-25 -> below dd resolution) */
 DM_INLINE dm_dd dm_dd_log(dm_dd a)
 {
     int e = dm_exponent(a.hi) - 1023;
@@ -354,7 +365,7 @@ DM_INLINE dm_dd dm_dd_log(dm_dd a)
     double ser = u * (2.0 + u2 * (2.0 / 3.0 + u2 * (2.0 / 5.0 + u2 * (2.0 / 7.0 + u2 * (2.0 / 9.0
                  + u2 * (2.0 / 11.0 + u2 * (2.0 / 13.0)))))));
     dm_dd y = dm_two_sum((double)e * DM_LN2_HI, ser);
-    for (int it = 0; it < 3; ++it) {                     /* y <- y + a*exp(-y) - 1 */
+    for (int it = 0; it < 2; ++it) {                     /* y <- y + a*exp(-y) - 1 */
         dm_dd ey = dm_dd_exp(dm_dd_neg(y));
         dm_dd c = dm_dd_sub(dm_dd_mul(a, ey), dm_dd_make(1.0, 0.0));
         y = dm_dd_add(y, c);

@@ -35,3 +35,8 @@ for nm, v in (("ATAN_0_5", mp.atan(mp.mpf(1) / 2)), ("ATAN_1", mp.atan(1)),
     hi = d(v); show(nm + "_HI", hi); show(nm + "_LO", d(v - mp.mpf(hi)))
 hi = d(pi / 4); show("PIO4_HI", hi)
 hi = d(mp.log(2)); show("LN2_HI", hi); show("LN2_LO", d(mp.log(2) - mp.mpf(hi)))
+print("/* double-double 1/k!, k = 2..11 (Taylor coefficients of dm_dd_expm1_reduced) */")
+for k in range(2, 12):
+    v = mp.mpf(1) / mp.factorial(k)
+    hi = d(v)
+    print(f"    {{ {hexs(hi)}, {hexs(d(v - mp.mpf(hi)))} }},   /* 1/{k}! */")

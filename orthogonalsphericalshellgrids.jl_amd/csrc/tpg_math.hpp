@@ -325,12 +325,22 @@ __device__ __noinline__ dd dd_expm1_reduced(dd a, int& kout)
     double kf = __builtin_rint(a.hi / kLn2Hi);
     dd r = dd_sub(a, dd_mul_d(ln2, kf));
     r.hi *= 0x1p-9; r.lo *= 0x1p-9;
-    dd term = r, s = r;
-    for (int n = 2; n <= 11; ++n) {
-        term = dd_mul(term, r);
-        term = dd_div(term, dd{ (double)n, 0.0 });
-        s = dd_add(s, term);
-    }
+    // Taylor to r^11/11!, Horner in double-double: s = r + r^2 (1/2! + r (1/3! + ...))
+    const dd invfact[10] = {
+    { 0x1.0000000000000p-1, 0x0.0p+0 },                // 1/2! 
+    { 0x1.5555555555555p-3, 0x1.5555555555555p-57 },   // 1/3! 
+    { 0x1.5555555555555p-5, 0x1.5555555555555p-59 },   // 1/4! 
+    { 0x1.1111111111111p-7, 0x1.1111111111111p-63 },   // 1/5! 
+    { 0x1.6c16c16c16c17p-10, -0x1.f49f49f49f49fp-65 }, // 1/6! 
+    { 0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-73 },  // 1/7! 
+    { 0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76 },  // 1/8! 
+    { 0x1.71de3a556c734p-19, -0x1.c154f8ddc6c00p-73 }, // 1/9! 
+    { 0x1.27e4fb7789f5cp-22, 0x1.cbbc05b4fa99ap-76 },  // 1/10!
+    { 0x1.ae64567f544e4p-26, -0x1.c062e06d1f209p-80 }, // 1/11!
+    };
+    dd pl = invfact[9];
+    for (int n = 8; n >= 0; --n) pl = dd_add(invfact[n], dd_mul(r, pl));
+    dd s = dd_add(r, dd_mul(dd_mul(r, r), pl));
     for (int i = 0; i < 9; ++i) s = dd_add(dd_mul_d(s, 2.0), dd_mul(s, s));
     kout = (int)kf;
     return s;
@@ -353,7 +363,7 @@ TPG_DEV dd dd_log(dd a)
     double ser = u * (2.0 + u2 * (2.0 / 3.0 + u2 * (2.0 / 5.0 + u2 * (2.0 / 7.0 + u2 * (2.0 / 9.0
                  + u2 * (2.0 / 11.0 + u2 * (2.0 / 13.0)))))));
     dd y = two_sum((double)e * kLn2Hi, ser);
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < 2; ++it) {
         dd ey = dd_exp(dd_neg(y));
         dd c = dd_sub(dd_mul(a, ey), dd{ 1.0, 0.0 });
         y = dd_add(y, c);
