@@ -68,7 +68,9 @@ def test_reference_row_symmetry_testset(osg, gpu):
 
 GEOMS = [((10, 10, 1), (4, 4, 4)), ((60, 30, 3), (4, 4, 4)), ((62, 31, 2), (3, 2, 1)),   # odd Hx -> scalar kernel
          ((256, 40, 4), (4, 4, 2)), ((1000, 50, 2), (4, 4, 4)), ((130, 20, 3), (2, 5, 0)),
-         ((6, 7, 1), (4, 4, 1)), ((4, 4, 2), (4, 4, 1))]
+         ((6, 7, 1), (4, 4, 1)), ((4, 4, 2), (4, 4, 1)),
+         ((64, 40, 1), (4, 13, 1)),      # extended north halo of the split-explicit free surface (test/runtests.jl:61-71): Hy > 8
+         ((3600, 24, 2), (4, 4, 4))]     # full 1/10 degree rows
 
 
 @pytest.mark.parametrize("size,halo", GEOMS, ids=[f"{s}-{h}" for s, h in GEOMS])
@@ -82,6 +84,23 @@ def test_fill_halo_regions_parity(osg, oracle, gpu, size, halo, dtype):
     for f, h, (xl, yl, sg) in zip(fs, hosts, specs):
         oracle.fill_halo_regions(h, xl, yl, sg, size, halo)
         assert np.array_equal(f.data.cpu().numpy(), h), (xl, yl, sg)
+
+
+def test_mixed_geometries_in_one_call(osg, oracle, gpu):
+    """a tupled fill_halo_regions!((u, v, c, eta)) mixes 3-D fields with a reduced (Nz = 1, Hz = 0) one"""
+    size, halo = (60, 30, 3), (4, 4, 4)
+    grid = osg.TripolarGrid(size=size, halo=halo)
+    rng = np.random.default_rng(8)
+    u, v, c = osg.XFaceField(grid), osg.YFaceField(grid), osg.CenterField(grid)
+    eta = osg.Field((osg.Center, osg.Center, None), grid)
+    hosts = []
+    for f in (u, v, c, eta):
+        h = rng.uniform(-1, 1, tuple(f.data.shape)); f.data.copy_(torch.from_numpy(h)); hosts.append(h)
+    osg.fill_halo_regions((u, v, c, eta))
+    for f, h, (xl, yl, sg) in zip((u, v, c, eta), hosts, ((1, 0, -1), (0, 1, -1), (0, 0, 1), (0, 0, 1))):
+        sz = (size[0], size[1], f.Nz); hl = (halo[0], halo[1], f.Hz)
+        oracle.fill_halo_regions(h, xl, yl, sg, sz, hl)
+        assert np.array_equal(f.data.cpu().numpy(), h), f.loc
 
 
 def test_zipper_only_and_level_range(osg, oracle, gpu):
