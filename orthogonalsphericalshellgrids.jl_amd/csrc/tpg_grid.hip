@@ -432,10 +432,23 @@ struct Step4 {           // the 4 points a step creates: k = 0 FC(jc), 1 CC(jc),
 
 struct LaneConst { double aslF, aclF, aslC, aclC, hemi; };
 
-__device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc, int jc, int jf, Step4& s, const double* atab)
+struct RowTab { double shC, chC, shF, chF; };    // sinh/cosh(psi) of Center row jc and Face row jf: wave-uniform
+
+// Scalar (s_load) read of the psi tables: the row index is wave-uniform and the tables were written by
+// the previous kernel, so they can be read through the constant address space into SGPRs -- no VGPRs,
+// and issued one row ahead so the latency never sits on the critical path.
+typedef const double __attribute__((address_space(4))) kconst_double;
+__device__ __forceinline__ RowTab load_rowtab(const GridK& g, int jc, int jf)
 {
-    const double shC = g.tj[2 * g.Ny + jc - 1], chC = g.tj[3 * g.Ny + jc - 1];
-    const double shF = g.tj[0 * g.Ny + jf - 1], chF = g.tj[1 * g.Ny + jf - 1];
+    kconst_double* tj = (kconst_double*)g.tj;
+    jc = __builtin_amdgcn_readfirstlane(jc < 1 ? 1 : (jc > g.Ny ? g.Ny : jc));
+    jf = __builtin_amdgcn_readfirstlane(jf < 1 ? 1 : (jf > g.Ny ? g.Ny : jf));
+    return RowTab{ tj[2 * g.Ny + jc - 1], tj[3 * g.Ny + jc - 1], tj[0 * g.Ny + jf - 1], tj[1 * g.Ny + jf - 1] };
+}
+
+__device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc, const RowTab& rt, Step4& s, const double* atab)
+{
+    const double shC = rt.shC, chC = rt.chC, shF = rt.shF, chF = rt.chF;
     double x[4] = { lc.aslF * chC, lc.aslC * chC, lc.aslF * chF, lc.aslC * chF };          // :67
     double y[4] = { lc.aclF * shC, lc.aclC * shC, lc.aclF * shF, lc.aclC * shF };          // :68
     double q[4], rr[4], at1[4], at2[4];
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
     {
         Step4 s;
         // prologue: FC, CC on row jlo-1; FF, CF on row jlo
-        if (jlo - 1 >= 1 && jlo - 1 < g.Ny && small_lon) points_fast(g, lc, jlo - 1, jlo, s, atab);
+        if (jlo - 1 >= 1 && jlo - 1 < g.Ny && small_lon) points_fast(g, lc, load_rowtab(g, jlo - 1, jlo), s, atab);
         else { Step4 tmp; points_general(g, i, jlo - 1, jlo, tmp); s = tmp; }   // only tmp is address-taken
         if (emit) {
             long long off = rowoff(jlo);
@@ -527,9 +540,12 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
         cfWP = Nb{ shf<-1>(cfP.lam), shf<-1>(cfP.a), shf<-1>(cfP.ca) };
     }
 
+    RowTab rt = load_rowtab(g, jlo, jlo + 1);
     for (int j = jlo; j <= jhi; ++j) {
         Step4 s;
-        if (j < g.Ny && small_lon) points_fast(g, lc, j, j + 1, s, atab);
+        const RowTab rt_now = rt;
+        rt = load_rowtab(g, j + 1, j + 2);                         // prefetch the next row's values
+        if (j < g.Ny && small_lon) points_fast(g, lc, rt_now, s, atab);
         else { Step4 tmp; points_general(g, i, j, j + 1, tmp); s = tmp; }
         if (emit) {
             long long off = rowoff(j);
