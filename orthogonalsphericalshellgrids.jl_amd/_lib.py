@@ -70,6 +70,7 @@ SIGNATURES = {
     "tpg_pack_y_halo": (_i, [C.POINTER(_vp), _i, _vp, _i] + _geom + [_i, _vp]),
     "tpg_unpack_y_halo": (_i, [C.POINTER(_vp), _i, _vp, _i] + _geom + [_i, _vp]),
     "tpg_fill_synthetic": (_i, [_vp, C.c_uint64, C.c_double] + _geom + [_i, _vp]),
+    "tpg_math_probe": (_i, [_i, _vp, _vp, _vp, C.c_longlong, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,114 @@
+"""Argument-by-argument bit identity of the deterministic Float64 math:
+  (a) device scalar functions (csrc/tpg_math.hpp)  ==  oracle functions (oracle/detmath.h);
+  (b) device batch forms (csrc/tpg_batch.hpp)      ==  device scalar functions on their fast domain,
+      with the `rare` flag raised exactly outside it.
+This is what makes the GPU grid bit-identical to the CPU restatement by construction."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N = 400_000
+SCALAR = {"sin": 0, "cos": 1, "sind": 2, "cosd": 3, "tand": 4, "atan": 5, "asin": 6, "asinh": 7, "sinh": 8, "cosh": 9}
+SPECIAL = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 45.0, -45.0, 90.0, -90.0, 135.0, 180.0, -180.0, 225.0, 270.0, 315.0,
+                    359.99999999999994, 0.4375, 0.6875, 1.1875, 2.4375, 2.0 ** -27, 2.0 ** -26, 2.0 ** 66, 1e300,
+                    np.inf, -np.inf, np.pi / 4, -np.pi / 4, np.nextafter(np.pi / 4, 1), np.pi / 2, np.pi, -np.pi,
+                    np.nextafter(np.pi, 0), 0.975, 0.9999999999999999, 5e-324, 1e-310])
+
+
+def probe(osg, gpu, which, x):
+    lib = osg._lib.lib()
+    xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(gpu)
+    yd = torch.empty_like(xd)
+    rd = torch.zeros(xd.numel(), dtype=torch.int32, device=gpu)
+    assert lib.tpg_math_probe(which, xd.data_ptr(), yd.data_ptr(), rd.data_ptr(), xd.numel(), None) == 0
+    torch.cuda.synchronize()
+    return yd.cpu().numpy(), rd.cpu().numpy().astype(bool)
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+
+
+def args_for(name, rng):
+    u = rng.uniform
+    parts = {
+        "sin": [u(-4, 4, N), np.pi + u(-1e-6, 1e-6, 2000), u(-1e-3, 1e-3, N // 4), 10.0 ** u(-300, -5, 2000)],
+        "cos": [u(-4, 4, N), np.pi / 2 + u(-1e-9, 1e-9, 2000), u(-1e-3, 1e-3, N // 4)],
+        "sind": [u(-400, 400, N), np.arange(-720, 721, 15.0), u(-1e-9, 1e-9, 2000)],
+        "cosd": [u(-400, 400, N), np.arange(-720, 721, 15.0), 90 + u(-1e-9, 1e-9, 2000)],
+        "tand": [u(0, 89, N // 2)],
+        "atan": [u(-5, 5, N), 10.0 ** u(-40, 40, N // 4) * rng.choice([-1, 1], N // 4)],
+        "asin": [u(-1, 1, N), 10.0 ** u(-30, 0, N // 4), 1 - 10.0 ** u(-16, -1, 5000)],
+        "asinh": [u(0, 40, 20000), 10.0 ** u(-12, 1, 20000)],
+        "sinh": [u(0, 6, 20000), 10.0 ** u(-12, 0, 20000)],
+        "cosh": [u(0, 6, 20000), 10.0 ** u(-12, 0, 20000)],
+    }[name]
+    sp = SPECIAL if name not in ("asinh", "sinh", "cosh", "tand") else np.array([0.0, 1.0, 2.0, 1e-8])
+    if name in ("sin", "cos"):
+        sp = sp[np.abs(sp) < 1e6]
+    if name in ("sind", "cosd"):
+        sp = sp[np.isfinite(sp)]
+    if name == "asin":
+        sp = sp[np.abs(sp) <= 1]
+    return np.concatenate(parts + [sp])
+
+
+@pytest.mark.parametrize("name", list(SCALAR))
+def test_device_scalar_equals_oracle(osg, oracle, gpu, name):
+    x = args_for(name, np.random.default_rng(sum(map(ord, name))))
+    got, _ = probe(osg, gpu, SCALAR[name], x)
+    want = oracle.math_probe(name, x)
+    bad = ~same_bits(got, want)
+    assert not bad.any(), (f"{name}: {bad.sum()} of {x.size} differ, e.g. x={x[bad][:3]!r} "
+                           f"got={got[bad][:3]!r} want={want[bad][:3]!r}")
+
+
+def _sp(pred):
+    return SPECIAL[pred(SPECIAL)]
+
+
+BATCH = [
+    # (batch probe id, scalar probe id, argument generator, fast domain: predicate | None (everywhere) | "flag")
+    (100, 0, lambda r: np.concatenate([r.uniform(-1.2, 1.2, N), r.uniform(-1e-3, 1e-3, N // 2),
+                                       10.0 ** r.uniform(-320, -5, 4000), _sp(lambda s: np.abs(s) < 4)]),
+     lambda x: np.abs(x) <= np.pi / 4),
+    (101, 1, lambda r: np.concatenate([r.uniform(-2.3, 2.3, N), np.pi / 2 + r.uniform(-1e-4, 1e-4, 4000),
+                                       np.array([0.0, -0.0, np.pi / 2, -np.pi / 2, np.pi / 4])]), "flag"),
+    (102, 5, lambda r: np.concatenate([r.uniform(-5, 5, N), 10.0 ** r.uniform(-40, 80, N // 4) * r.choice([-1, 1], N // 4),
+                                       SPECIAL]), None),
+    (103, 5, lambda r: np.concatenate([r.uniform(-5, 5, N), 10.0 ** r.uniform(-40, 80, N // 4) * r.choice([-1, 1], N // 4),
+                                       SPECIAL]), None),
+    (104, 5, lambda r: np.concatenate([r.uniform(-0.6, 0.6, N), 10.0 ** r.uniform(-40, 0, N // 4), _sp(lambda s: np.abs(s) < 2)]),
+     lambda x: np.abs(x) < 0.4375),
+    (105, 6, lambda r: np.concatenate([r.uniform(-0.7, 0.7, N), 10.0 ** r.uniform(-40, 0, N // 4), _sp(lambda s: np.abs(s) <= 1)]),
+     lambda x: np.abs(x) < 0.5),
+    (106, 2, lambda r: np.concatenate([r.uniform(-359.9, 359.9, N), np.arange(-345, 346, 15.0),
+                                       np.array([0.0, -0.0, 359.99999999999994])]), None),
+    (107, 3, lambda r: np.concatenate([r.uniform(-359.9, 359.9, N), np.arange(-345, 346, 15.0),
+                                       np.array([0.0, -0.0, 359.99999999999994])]), None),
+]
+
+
+@pytest.mark.parametrize("bid,sid,gen,domain", BATCH, ids=[str(b[0]) for b in BATCH])
+def test_batch_form_equals_scalar(osg, gpu, bid, sid, gen, domain):
+    x = gen(np.random.default_rng(bid))
+    x = np.ascontiguousarray(x[: (x.size // 4) * 4])   # whole groups of 4 (the flag is per group)
+    got, rare = probe(osg, gpu, bid, x)
+    want, _ = probe(osg, gpu, sid, x)
+    ok = same_bits(got, want)
+    if domain is None:
+        assert ok.all(), f"{(~ok).sum()} mismatches, e.g. x={x[~ok][:3]!r} got={got[~ok][:3]!r} want={want[~ok][:3]!r}"
+        return
+    if domain == "flag":                               # cos_b: wherever the group is not flagged the bits must match
+        bad = ~ok & ~rare
+        assert not bad.any(), f"{bad.sum()} unflagged mismatches, e.g. x={x[bad][:3]!r}"
+        assert rare.mean() < 0.02
+        return
+    inside = domain(x)
+    grp = inside.reshape(-1, 4).all(axis=1).repeat(4)  # a group is fast iff all 4 arguments are inside
+    bad = inside & ~ok
+    assert not bad.any(), f"{bad.sum()} mismatches inside the fast domain, e.g. x={x[bad][:3]!r} got={got[bad][:3]!r} want={want[bad][:3]!r}"
+    assert np.array_equal(rare, ~grp), "rare flag must be raised exactly for groups with an outside argument"
