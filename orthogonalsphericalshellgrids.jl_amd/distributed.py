@@ -58,6 +58,21 @@ def message_shape(nfields, f):
     return (nfields, f.Nz + 2 * f.Hz, f.Hy, f.Nx + 2 * f.Hx)
 
 
+_BUFFERS: Dict[tuple, Dict[str, Dict[int, torch.Tensor]]] = {}
+
+
+def _message_buffers(shape, dtype, device, plan):
+    """send / recv message buffers, kept across fills (a halo fill runs every time step: no
+    allocator traffic on the hot path; one pair per seam side, geometry, dtype and device)"""
+    key = (tuple(shape), dtype, str(device), tuple(m.side for m in plan))
+    bufs = _BUFFERS.get(key)
+    if bufs is None:
+        bufs = {"send": {m.side: torch.empty(shape, dtype=dtype, device=device) for m in plan},
+                "recv": {m.side: torch.empty(shape, dtype=dtype, device=device) for m in plan}}
+        _BUFFERS[key] = bufs
+    return bufs["send"], bufs["recv"]
+
+
 def exchange_y_halos(fields, arch, transport: Optional[Callable] = None):
     """Fill the y-seam halo rows of `fields` (one geometry) from the neighbour ranks."""
     plan = exchange_plan(arch.local_rank, arch.ranks[1])
@@ -73,8 +88,7 @@ def exchange_y_halos(fields, arch, transport: Optional[Callable] = None):
         batch = fields[b0:b0 + _lib.TPG_MAX_FIELDS]
         ptrs = _lib.ptr_table([f.data for f in batch])
         shape = message_shape(len(batch), f0)
-        send = {m.side: torch.empty(shape, dtype=f0.data.dtype, device=dev) for m in plan}
-        recv = {m.side: torch.empty(shape, dtype=f0.data.dtype, device=dev) for m in plan}
+        send, recv = _message_buffers(shape, f0.data.dtype, dev, plan)
         with torch.cuda.device(dev):
             stream = _lib.current_stream_ptr(dev)
             for m in plan:
