@@ -746,9 +746,13 @@ template <typename T>
 int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStream_t s)
 {
     dim3 grid1(((g.Nx + 255) / 256) * (g.jm_hi - g.jm_lo + 1));
-    static const bool nt = getenv("TPG_BUILD_NT") ? atoi(getenv("TPG_BUILD_NT")) != 0 : true;
-    static const int variant = getenv("TPG_CELLS_VARIANT") ? atoi(getenv("TPG_CELLS_VARIANT")) : 2;
-    static const int strip_rows = getenv("TPG_CELLS_STRIP") ? atoi(getenv("TPG_CELLS_STRIP")) : 0;
+    // tuning / cross-check knobs, read per call (tests/test_gpu_variants.py switches them in-process):
+    //   TPG_CELLS_VARIANT 2 = k_cells_fast (default), 1 = k_cells_march, 0 = k_cells (thread per cell)
+    //   TPG_BUILD_NT      1 = streaming stores (default), 0 = plain stores
+    //   TPG_CELLS_STRIP   rows per strip of the marching kernels (default: one resident round)
+    const bool nt = getenv("TPG_BUILD_NT") ? atoi(getenv("TPG_BUILD_NT")) != 0 : true;
+    const int variant = getenv("TPG_CELLS_VARIANT") ? atoi(getenv("TPG_CELLS_VARIANT")) : 2;
+    const int strip_rows = getenv("TPG_CELLS_STRIP") ? atoi(getenv("TPG_CELLS_STRIP")) : 0;
     if (variant == 1 || variant == 2) {
         // strips sized so that the whole grid is (just under) one resident round of waves:
         // equal work per wave, no tail; short strips cost one extra point row each
