@@ -11,7 +11,9 @@ One "step" = one pass of the hot path over one batch of synthetic input, residen
       v(CF,-1) zeta(FF,+1): zipper fold (ONE batched launch; north rank only) + periodic x
       (+ for N > 1 the y-seam exchange of Hy rows with the neighbour ranks over RCCL send/recv).
 N > 1 is WEAK scaling: every rank keeps a 3600 x 1800 x 75 band of a 3600 x (1800 N) x 75 global
-tripolar grid (latitude bands, src/distributed_tripolar_grid.jl); no data-path collective.
+tripolar grid (latitude bands, src/distributed_tripolar_grid.jl); no data-path collective.  For N > 1
+the step is ordered zipper -> periodic x -> [seam exchange on a side stream || grid build]: the
+exchange only needs the filled fields, the build only writes the grid arrays.
 
 value = horizontal grid cells of all ranks / step time (max over ranks).  `roofline` is the zipper
 kernel (the HBM-bound kernel BASELINE.json's north_star sets the 70 % target on); the precompute
@@ -163,20 +165,48 @@ def main():
         _lib.check(lib.tpg_event_create(C.byref(e)))
         return e
 
-    def step(marks=None, zev=None):
+    def zipper(zev):
+        if not north_rank:
+            return
+        if zev is not None:         # the kernel's own start/stop device timestamps (hipExtLaunchKernelGGL)
+            _lib.check(lib.tpg_zipper_fill_timed(fptrs, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F64, stream, zev[0], zev[1]))
+        else:
+            _lib.check(lib.tpg_zipper_fill(fptrs, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F64, stream))
+
+    def step_serial(marks=None, zev=None):
+        """N = 1: build -> zipper -> periodic x, one stream"""
         if marks is not None: marks[0].record()
         _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
         if marks is not None: marks[1].record()
-        if north_rank:
-            if zev is not None:     # the kernel's own start/stop device timestamps (hipExtLaunchKernelGGL)
-                _lib.check(lib.tpg_zipper_fill_timed(fptrs, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F64, stream, zev[0], zev[1]))
-            else:
-                _lib.check(lib.tpg_zipper_fill(fptrs, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F64, stream))
+        zipper(zev)
         if marks is not None: marks[2].record()
         _lib.check(lib.tpg_periodic_x_fill(fptrs, n, *geom, _lib.TPG_F64, stream))
-        if world > 1:
-            exchange_y_halos(band_fields, arch, transport=transport)
         if marks is not None: marks[3].record()
+
+    main_stream = torch.cuda.current_stream(dev)
+    side_stream = torch.cuda.Stream(dev) if world > 1 else None
+    if world > 1:
+        # the build shares the GPU with RCCL's send/recv workgroups: plan its single resident round
+        # for 90 % of the wave slots (see TPG_CELLS_CAPACITY in csrc/tpg_grid.hip)
+        os.environ.setdefault("TPG_CELLS_CAPACITY", "0.9")
+
+    def step_overlapped(marks=None, zev=None):
+        """N > 1: the halo fill's seam exchange (pack -> RCCL send/recv -> unpack, side stream) runs
+        concurrently with the grid build (main stream); the two touch disjoint memory.
+        marks: [0] start, [1] after the zipper, [2] after periodic x, [3] end of the build (main stream)"""
+        if marks is not None: marks[0].record()
+        zipper(zev)
+        if marks is not None: marks[1].record()
+        _lib.check(lib.tpg_periodic_x_fill(fptrs, n, *geom, _lib.TPG_F64, stream))
+        if marks is not None: marks[2].record()
+        side_stream.wait_stream(main_stream)
+        with torch.cuda.stream(side_stream):
+            exchange_y_halos(band_fields, arch, transport=transport)
+        _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
+        if marks is not None: marks[3].record()
+        main_stream.wait_stream(side_stream)
+
+    step = step_overlapped if world > 1 else step_serial
 
     def sync():
         torch.cuda.synchronize()
@@ -200,7 +230,10 @@ def main():
         elapsed = float(t.item())
 
     avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)      # ms
-    t_build, t_zip_bracket, t_rest = avg(0, 1), avg(1, 2), avg(2, 3)
+    if world > 1:      # overlapped step: marks are [start, zipper, periodic, build end]
+        t_zip_bracket, t_rest, t_build = avg(0, 1), avg(1, 2), avg(2, 3)
+    else:
+        t_build, t_zip_bracket, t_rest = avg(0, 1), avg(1, 2), avg(2, 3)
     t_zip = t_zip_bracket
     if north_rank:
         tot = 0.0
@@ -233,7 +266,9 @@ def main():
                        "global_size": list(gsize), "local_size": [NX, NY, NZ], "halo": [H, H, H], "fields": [s[0] for s in SPECS],
                        "parallelism": f"latitude-bands x{world}"},
             "precompute_cells_per_s": NX * NY / (t_build * 1e-3),
-            "precompute_ms": t_build, "zipper_ms": t_zip, "zipper_bracket_ms": t_zip_bracket, "periodic_and_exchange_ms": t_rest,
+            "precompute_ms": t_build, "zipper_ms": t_zip, "zipper_bracket_ms": t_zip_bracket,
+            "periodic_x_ms" if world > 1 else "periodic_and_exchange_ms": t_rest,
+            "overlap": "seam exchange on a side stream, concurrent with the grid build" if world > 1 else None,
             "zipper_GBps": zbytes / (t_zip * 1e-3) / 1e9,
         }
         traffic = None

@@ -750,6 +750,7 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
     //   TPG_CELLS_VARIANT 2 = k_cells_fast (default), 1 = k_cells_march, 0 = k_cells (thread per cell)
     //   TPG_BUILD_NT      1 = streaming stores (default), 0 = plain stores
     //   TPG_CELLS_STRIP   rows per strip of the marching kernels (default: one resident round)
+    //   TPG_CELLS_CAPACITY fraction of the wave slots that round may assume (default 1)
     const bool nt = getenv("TPG_BUILD_NT") ? atoi(getenv("TPG_BUILD_NT")) != 0 : true;
     const int variant = getenv("TPG_CELLS_VARIANT") ? atoi(getenv("TPG_CELLS_VARIANT")) : 2;
     const int strip_rows = getenv("TPG_CELLS_STRIP") ? atoi(getenv("TPG_CELLS_STRIP")) : 0;
@@ -771,7 +772,12 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
                 if (blocks < 1) blocks = 1;
                 resident_waves = cus * blocks * 4;
             }
-            int strips = resident_waves / m.nwx;
+            // TPG_CELLS_CAPACITY (0 < f <= 1): fraction of the wave slots to plan for -- below 1 when another
+            // kernel (e.g. RCCL send/recv of an overlapped halo exchange) shares the GPU, so that the
+            // build still fits one resident round instead of spilling a few blocks into a second one
+            double cap = getenv("TPG_CELLS_CAPACITY") ? atof(getenv("TPG_CELLS_CAPACITY")) : 1.0;
+            if (!(cap > 0.05 && cap <= 1.0)) cap = 1.0;
+            int strips = (int)(resident_waves * cap) / m.nwx;
             if (strips < 1) strips = 1;
             L = (nrows + strips - 1) / strips;
             if (L < 8) L = nrows < 8 ? nrows : 8;
