@@ -47,7 +47,7 @@ def test_zipper_kernel_variants_agree(osg, gpu, knob):
     specs = [(xl, yl, sg) for xl in (0, 1) for yl in (0, 1) for sg in (1, -1)]
     hosts = [rng.uniform(-1, 1, (4 + 4, 40 + 8, 256 + 8)) for _ in specs]
     outs = {}
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 1, 2, 3, 4, 5, 6, 7):
         knob["TPG_ZIPPER_VARIANT"] = str(variant)
         fs = []
         for (xl, yl, sg), h in zip(specs, hosts):
