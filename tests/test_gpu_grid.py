@@ -170,3 +170,33 @@ def test_workspace_too_small_is_an_error(osg, gpu):
     ws = torch.empty(64, dtype=torch.uint8, device=gpu)
     rc = lib.tpg_build_grid(C.byref(p), osg._lib.ptr_table(arrs), ws.data_ptr(), ws.numel(), None)
     assert rc == -4
+
+
+def test_randomised_parameters_against_the_oracle(osg, oracle, gpu):
+    """60 random (size, halo, poles, south, radius, dtype, band) configurations, bit-exact vs the oracle:
+    exercises the index maps on shapes no fixed case covers (Nx = 2, halo == size, bands of one row ...)."""
+    rng = np.random.default_rng(20261004)
+    for trial in range(60):
+        Nx = int(rng.choice([2, 4, 6, 8, 10, 12, 16, 30, 62, 64, 66, 124, 126, 130, 200]))
+        Ny = int(rng.integers(2, 41))
+        Hx = int(rng.integers(1, min(Nx, 6) + 1))
+        Hy = int(rng.integers(1, min(Ny, 6) + 1))
+        kw = dict(size=(Nx, Ny, 1), halo=(Hx, Hy, 1),
+                  north_poles_latitude=float(rng.choice([35, 55, 60.5, 75, 85])),
+                  first_pole_longitude=float(rng.choice([-180, -35.25, 0, 70, 90, 200, 359.5])),
+                  southernmost_latitude=float(rng.choice([-85, -80, -77.7, -60, 0, 20])),
+                  radius=float(rng.choice([1.0, 6371e3])))
+        dtype = np.float64 if trial % 4 else np.float32
+        tdt = torch.float64 if dtype == np.float64 else torch.float32
+        ref = oracle.build_grid(dtype=dtype, **kw)
+        g = osg.TripolarGrid(osg.GPU(0), tdt, **kw)
+        for name, r in ref.items():
+            assert np.array_equal(getattr(g, name).cpu().numpy(), r, equal_nan=True), (trial, kw, name)
+        if Ny >= 4 and trial % 3 == 0:              # a random latitude band of the same grid
+            R = int(rng.integers(2, min(Ny, 5) + 1))
+            r = int(rng.integers(0, R))
+            arch = osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=r)
+            band = osg.TripolarGrid(arch, tdt, **kw)
+            j0, j1 = band.jrange
+            for name, rr in ref.items():
+                assert np.array_equal(getattr(band, name).cpu().numpy(), rr[j0 - 1:j1 + 2 * Hy], equal_nan=True), (trial, kw, r, R, name)

@@ -196,3 +196,30 @@ def test_config3_tenth_degree_75_levels(osg, oracle, gpu):
         assert int(f[:, :Ny - 1].view(torch.int64).sum()) == ls
         assert bool((f[:, Ny + Hy:, :Hx] == 12345.0).all()) and bool((f[:Hz, Ny + Hy:] == 12345.0).all())
         assert not bool((f[Hz:Hz + Nz, Ny + Hy:, Hx:Hx + Nx] == 12345.0).any())     # every halo cell of the fold written
+
+
+def test_randomised_geometries_against_the_oracle(osg, oracle, gpu):
+    """80 random (Nx, Ny, Nz, halo, location, sign, dtype, level range) folds straight through the C ABI"""
+    lib = osg._lib.lib()
+    rng = np.random.default_rng(777)
+    for trial in range(80):
+        Nx = int(rng.choice([2, 4, 6, 8, 10, 14, 16, 30, 64, 66, 128, 130, 256, 258]))
+        Ny = int(rng.integers(1, 25))
+        Nz = int(rng.integers(1, 5))
+        Hx = int(rng.integers(0, min(Nx, 6) + 1))
+        Hy = int(rng.integers(0, min(Ny, 9) + 1))
+        Hz = int(rng.integers(0, 3))
+        xl, yl = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        sgn = int(rng.choice([1, -1, 2, -3]))                       # bc.condition is any Int in the reference
+        dt, tdt, ft = ((np.float64, torch.float64, 1), (np.float32, torch.float32, 0))[trial % 2]
+        kstart = int(rng.integers(1 - Hz, Nz + 1))
+        kcount = int(rng.integers(0, Nz + Hz - kstart + 2))
+        h = rng.uniform(-1, 1, (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)).astype(dt)
+        d = torch.from_numpy(h).to(gpu)
+        rc = lib.tpg_zipper_fill(osg._lib.ptr_table([d]), 1, (C.c_int8 * 1)(xl), (C.c_int8 * 1)(yl), (C.c_int32 * 1)(sgn),
+                                 Nx, Ny, Nz, Hx, Hy, Hz, kstart, kcount, ft, None)
+        assert rc == 0, (trial, lib.tpg_last_error())
+        torch.cuda.synchronize()
+        if Hy > 0 and kcount > 0:
+            oracle.zipper_fill(h, xl, yl, sgn, (Nx, Ny, Nz), (Hx, Hy, Hz), kstart, kcount)
+        assert np.array_equal(d.cpu().numpy(), h), (trial, Nx, Ny, Nz, Hx, Hy, Hz, xl, yl, sgn, kstart, kcount)
