@@ -8,11 +8,20 @@
 //   K0 tables      : per-i  a*sind(lambda), a*cosd(lambda) (Face, Center; the Nlambda/4 circshift is
 //                    folded into the index), per-j sinh(psi), cosh(psi) latitude-stretching tables
 //                    (Face, Center), and the (Hy+1)-row lat-lon continuation table.  O(Nx+Ny) work.
-//   K1 cells       : one thread per interior cell (i, j) of the rank's row band: evaluates the
-//                    Murray (1996) map at the 4 staggered locations of the cell and of its stencil
-//                    neighbours THROUGH the halo index maps (periodic x, zipper fold, row-Ny
-//                    substitution, zero south halo), then the 8 haversine edge lengths, 2
-//                    spherical quadrilateral areas and 2 product areas; stores 8 + 12 values.
+//   K1 cells       : every interior cell (i, j) of the rank's row band: the Murray (1996) map at the 4
+//                    staggered locations of the cell and of its stencil neighbours THROUGH the halo
+//                    index maps (periodic x, zipper fold, row-Ny substitution, zero south halo),
+//                    then the 8 haversine edge lengths, 2 spherical quadrilateral areas and 2
+//                    product areas; stores 8 + 12 values.  Three forms with identical arithmetic
+//                    (tests/test_gpu_variants.py), selected by TPG_CELLS_VARIANT:
+//                      2  k_cells_fast   DEFAULT.  Waves of 62 columns march north over a strip of
+//                                        rows; each staggered point is evaluated once, kept in
+//                                        registers, shared with the neighbour lanes by shuffles;
+//                                        transcendentals as straight-line batches (tpg_batch.hpp).
+//                      1  k_cells_march  same marching scheme on the scalar functions; also the
+//                                        path for |first_pole_longitude + 90| > 360 inside (2).
+//                      0  k_cells        one thread per cell, everything recomputed: the simple
+//                                        reference form the other two are checked against.
 //   K2 halos       : compact pass over halo cells only (x-halo columns, north fold rows, zero
 //                    south rows of the coordinates, row-Ny substitution of the y-Center metrics).
 //   K3 south       : lat-lon continuation rows j = 1-Hy..1 of the 12 metrics (south rank only).
