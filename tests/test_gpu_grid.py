@@ -200,3 +200,23 @@ def test_randomised_parameters_against_the_oracle(osg, oracle, gpu):
             j0, j1 = band.jrange
             for name, rr in ref.items():
                 assert np.array_equal(getattr(band, name).cpu().numpy(), rr[j0 - 1:j1 + 2 * Hy], equal_nan=True), (trial, kw, r, R, name)
+
+
+def test_orthogonality_of_the_device_built_grid(osg, gpu):
+    """test/test_tripolar_grid.jl:36-76 on the HIP-built 1 degree grid (poles 75E / 35N): the chord
+    angle at every FF node (5-degree pole boxes and phi < -78 masked, as the reference's immersed
+    mask does) deviates from 90 degrees by less than 2 degrees.  The reference bounds it by a
+    cubed-sphere panel's range; that grid generator is Oceananigans-internal (see test_oracle_kat)."""
+    Nx, Ny, H = 360, 180, 4
+    g = osg.TripolarGrid(size=(Nx, Ny, 1), first_pole_longitude=75, north_poles_latitude=35)
+    lam, phi = torch.deg2rad(g.lambda_ff), torch.deg2rad(g.phi_ff)
+    xyz = [torch.cos(lam) * torch.cos(phi), torch.sin(lam) * torch.cos(phi), torch.sin(phi)]
+    sl = lambda a, di, dj: a[H + dj:H + Ny - 1 + dj, H + di:H + Nx - 1 + di]
+    v1 = torch.stack([sl(a, 1, 0) - sl(a, 0, 0) for a in xyz])
+    v2 = torch.stack([sl(a, 0, 1) - sl(a, 0, 0) for a in xyz])
+    cos = (v1 * v2).sum(0) / torch.sqrt((v1 * v1).sum(0) * (v2 * v2).sum(0))
+    ang = torch.rad2deg(torch.acos(cos)) - 90
+    L, P = sl(g.lambda_ff, 0, 0), sl(g.phi_ff, 0, 0)
+    mask = ((abs(L - 75) < 5) & (abs(35 - P) < 5)) | ((abs(L - 255) < 5) & (abs(35 - P) < 5)) | (P < -78)
+    ang = torch.where(mask, torch.zeros_like(ang), ang)
+    assert float(ang.max()) < 2.0 and float(ang.min()) > -2.0
