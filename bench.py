@@ -292,7 +292,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             threads = 1
             line["cpu_baseline"] = cpu_baseline(threads)
-        print(json.dumps(line, ensure_ascii=False))
+        print(json.dumps(line))          # ASCII-escaped: safe under any stdout encoding
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
