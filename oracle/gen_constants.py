@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE (oracle side).  Run:  python oracle/gen_constants.py
 The minimax polynomial coefficients (sin/cos/atan/asin kernels, FreeBSD msun family) are not
 derivable; they are validated instead by tests/test_detmath.py against mpmath to <1 ulp.
 """
-import mpmath as mp, struct
+import mpmath as mp
 mp.mp.prec = 700
 
 def d(x):            # round-to-nearest double

@@ -8,7 +8,6 @@ send/recv over xGMI (torch.distributed backend "nccl"); gathering / scattering b
 fields and the contiguous message is done by the HIP kernels tpg_pack_y_halo / tpg_unpack_y_halo.
 No collective is involved: a y-slab chain only ever talks to its two neighbours.
 """
-import ctypes as C
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional
 

@@ -7,7 +7,6 @@ Field data is one torch tensor of shape (Nz'+2Hz, Ny+2Hy, Nx+2Hx) in HBM whose m
 one geometry into ONE zipper launch + one periodic-x launch (tpg_fill_halo_regions).
 """
 import ctypes as C
-from typing import Iterable, Optional
 
 import torch
 

@@ -7,7 +7,7 @@ device memory.  torch is used for device allocations / streams only.
 """
 import ctypes as C
 import unicodedata
-from dataclasses import dataclass, field as dc_field
+from dataclasses import dataclass
 from typing import Any, Optional, Sequence, Tuple
 
 import torch

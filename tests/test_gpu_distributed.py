@@ -15,7 +15,6 @@ SPECS = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype):
     from orthogonalsphericalshellgrids.jl_amd import fields as F
-    from orthogonalsphericalshellgrids.jl_amd.distributed import exchange_plan, message_shape
     size, halo = (48, 40, 3), (4, 4, 2)
     (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
     tdt = torch.float64 if dtype == np.float64 else torch.float32
@@ -60,7 +59,6 @@ def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype):
         # run the product's fill up to the transport; unpack happens after all ranks have "sent"
         F.fill_halo_regions(fs, exchange=make_transport(r))
     # the unpack inside fill_halo_regions ran on not-yet-delivered buffers; deliver and unpack again
-    import ctypes as C
     for me, plan, recv in pending:
         arch, grid, fs = ranks[me]
         f0 = fs[0]
@@ -81,7 +79,6 @@ def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype):
 
 def test_pack_unpack_roundtrip_and_layout(osg, gpu):
     """message layout [field][level][Hy][sx]; pack reads interior rows, unpack writes halo rows"""
-    import ctypes as C
     lib = osg._lib.lib()
     size, halo = (20, 12, 2), (4, 3, 1)
     (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo

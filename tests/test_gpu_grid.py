@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import A, interior, max_rel_err
+from helpers import max_rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12     # relative, Float64 metrics (north_star)
