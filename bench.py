@@ -206,7 +206,21 @@ def main():
         if marks is not None: marks[3].record()
         main_stream.wait_stream(side_stream)
 
-    step = step_overlapped if world > 1 else step_serial
+    def step_serial_exchange(marks=None, zev=None):
+        """N > 1 without overlap (TPG_BENCH_OVERLAP=0): same work, one stream"""
+        if marks is not None: marks[0].record()
+        zipper(zev)
+        if marks is not None: marks[1].record()
+        _lib.check(lib.tpg_periodic_x_fill(fptrs, n, *geom, _lib.TPG_F64, stream))
+        if marks is not None: marks[2].record()
+        exchange_y_halos(band_fields, arch, transport=transport)
+        _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
+        if marks is not None: marks[3].record()
+
+    overlap = world > 1 and os.environ.get("TPG_BENCH_OVERLAP", "1") != "0"
+    if world > 1 and not overlap:
+        os.environ["TPG_CELLS_CAPACITY"] = "1.0"
+    step = step_overlapped if overlap else (step_serial_exchange if world > 1 else step_serial)
 
     def sync():
         torch.cuda.synchronize()
@@ -268,7 +282,7 @@ def main():
             "precompute_cells_per_s": NX * NY / (t_build * 1e-3),
             "precompute_ms": t_build, "zipper_ms": t_zip, "zipper_bracket_ms": t_zip_bracket,
             "periodic_x_ms" if world > 1 else "periodic_and_exchange_ms": t_rest,
-            "overlap": "seam exchange on a side stream, concurrent with the grid build" if world > 1 else None,
+            "overlap": "seam exchange on a side stream, concurrent with the grid build" if overlap else None,
             "zipper_GBps": zbytes / (t_zip * 1e-3) / 1e9,
         }
         traffic = None
