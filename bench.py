@@ -88,6 +88,14 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if not os.path.exists(os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "libtripolar_hip.so")):
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:            # fresh checkout: build once (hipcc, gcc)
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            while not os.path.exists(os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "libtripolar_hip.so")):
+                time.sleep(1.0)
+            time.sleep(2.0)
     import orthogonalsphericalshellgrids.jl_amd as osg
     from orthogonalsphericalshellgrids.jl_amd import _lib
     from orthogonalsphericalshellgrids.jl_amd.distributed import exchange_y_halos

@@ -6,6 +6,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -40,7 +41,7 @@ def build_library(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("tpg_oracle.c", "detmath.h")):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=sys.stderr)
     return _LIB_PATH
 
 
