@@ -484,6 +484,48 @@ __device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc,
     s.X[1] = cs[2] * cs[3]; s.Y[1] = sn[2] * cs[3]; s.Z[1] = sn[3];      // FF
 }
 
+// same arithmetic in batches of 2 (for kernels that run 4 waves/SIMD and must stay under 128 VGPRs)
+__device__ __forceinline__ void points_fast2(const GridK& g, const LaneConst& lc, const RowTab& rt, Step4& s, const double* atab)
+{
+    const double shC = rt.shC, chC = rt.chC, shF = rt.shF, chF = rt.chF;
+    double x[4] = { lc.aslF * chC, lc.aslC * chC, lc.aslF * chF, lc.aslC * chF };          // :67
+    double y[4] = { lc.aclF * shC, lc.aclC * shC, lc.aclF * shF, lc.aclC * shF };          // :68
+    double q[4], rr[4], at1[4], at2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt(y[k] * y[k] + x[k] * x[k]); }
+#pragma unroll
+    for (int h = 0; h < 4; h += 2) {
+        double qa[2] = { q[h], q[h + 1] }, ra[2] = { rr[h], rr[h + 1] }, o1[2], o2[2];
+        tpgb::atan_tab_b<2>(qa, o1, atab);
+        tpgb::atan_tab_b<2>(ra, o2, atab);
+        at1[h] = o1[0]; at1[h + 1] = o1[1]; at2[h] = o2[0]; at2[h + 1] = o2[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double l = -kC180Pi * at1[k];                          // :77 (no pole below row Ny)
+        s.phi[k] = 90.0 - kC360Pi * at2[k];                    // :78
+        l += lc.hemi;                                          // :82
+        l += g.fplp90;                                         // :86
+        s.lam[k] = tpgb::fmod360_small(tpgb::fmod360_small(l) + 360.0);   // :87
+        s.a[k] = s.phi[k] * kDeg2Rad;
+    }
+    double sn[4], cs[4];
+#pragma unroll
+    for (int h = 0; h < 4; h += 2) {
+        double aa[2] = { s.a[h], s.a[h + 1] }, cc2[2];
+        if (tpgb::cos_b<2>(aa, cc2)) { cc2[0] = cosD(aa[0]); cc2[1] = cosD(aa[1]); }
+        s.ca[h] = cc2[0]; s.ca[h + 1] = cc2[1];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {        // h = 0: CC (lam[1], phi[1]);  h = 1: FF (lam[2], phi[2])
+        double ang2[2] = { s.lam[1 + h], s.phi[1 + h] }, sn2[2], cs2[2];
+        tpgb::sincosd_b<2>(ang2, sn2, cs2);
+        sn[2 * h] = sn2[0]; sn[2 * h + 1] = sn2[1]; cs[2 * h] = cs2[0]; cs[2 * h + 1] = cs2[1];
+    }
+    s.X[0] = cs[0] * cs[1]; s.Y[0] = sn[0] * cs[1]; s.Z[0] = sn[1];      // CC
+    s.X[1] = cs[2] * cs[3]; s.Y[1] = sn[2] * cs[3]; s.Z[1] = sn[3];      // FF
+}
+
 // general rows (row Ny: fold, substitution, pole; row 0: zero south halo) through coord()
 __device__ __noinline__ void points_general(const GridK& g, int i, int jc, int jf, Step4& s)
 {
@@ -534,7 +576,8 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
         Step4 s;
         // prologue: FC, CC on row jlo-1; FF, CF on row jlo
         if (jlo - 1 >= 1 && jlo - 1 < g.Ny && small_lon) points_fast(g, lc, load_rowtab(g, jlo - 1, jlo), s, atab);
-        else { Step4 tmp; points_general(g, i, jlo - 1, jlo, tmp); s = tmp; }   // only tmp is address-taken
+        else { Step4 tmp; GridK gc = g; points_general(gc, i, jlo - 1, jlo, tmp); s = tmp; }   // only the copies are address-taken:
+                                                                                          // g itself stays in SGPRs (kernarg)
         if (emit) {
             long long off = rowoff(jlo);
             put<T, NT>(o, TPG_LAMBDA_FF, off, s.lam[2]); put<T, NT>(o, TPG_PHI_FF, off, s.phi[2]);
@@ -555,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
         const RowTab rt_now = rt;
         rt = load_rowtab(g, j + 1, j + 2);                         // prefetch the next row's values
         if (j < g.Ny && small_lon) points_fast(g, lc, rt_now, s, atab);
-        else { Step4 tmp; points_general(g, i, j, j + 1, tmp); s = tmp; }
+        else { Step4 tmp; GridK gc = g; points_general(gc, i, j, j + 1, tmp); s = tmp; }
         if (emit) {
             long long off = rowoff(j);
             put<T, NT>(o, TPG_LAMBDA_FC, off, s.lam[0]); put<T, NT>(o, TPG_PHI_FC, off, s.phi[0]);
@@ -650,6 +693,164 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
         fcP = fc; ccP = cc; ffP = ff; cfP = cf;
         ccWP = ccW; ffEP = ffE; cfWP = cfW;
     }
+}
+
+// ---- K1 (tile form): 64 x R point sets per block through LDS, 4 waves per SIMD -------------------
+// The marching kernels need ~70 live doubles per lane (two rows of points + neighbours) and run at 2
+// waves/SIMD, where dependent FP64 chains leave the VALU idle ~28 % of the time (PMC); the plain
+// thread-per-cell kernel at 4 waves/SIMD is 95 % busy.  This form keeps the work-sharing but not the
+// register state: a block of 64 x R threads evaluates one point set per thread (step s = FC(s), CC(s),
+// FF(s+1), CF(s+1), exactly as one marching step), parks {lambda, a, cos a[, X, Y, Z]} in LDS
+// (18 doubles x 64 x R), and after ONE barrier every thread with a south and east/west neighbour
+// inside the tile computes its cell from its own registers plus 51 LDS reads.  Row p = 0 and lanes
+// 0 / 63 are aprons (tiles overlap by one point row / two columns): (R-1)/R x 62/64 of the lanes emit.
+// A wave owns one point row, so the special rows (0, Ny) are a wave-uniform branch to coord().
+// Same arithmetic as the other K1 forms: bit-identical results.
+template <int R> struct TileLds { double v[18][R][64]; };
+enum { L_FC = 0, L_CC = 3, L_FF = 9, L_CF = 15 };    // field bases: FC(lam,a,ca) CC(lam,a,ca,X,Y,Z) FF(6) CF(3)
+
+template <typename T, bool NT, int R>
+__global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, int tiles_x)
+{
+    __shared__ __attribute__((aligned(16))) double atab[TPG_ATAN_TABLE_DOUBLES];
+    __shared__ TileLds<R> lds;
+    tpgb::atan_table_init(atab, threadIdx.x);
+    __syncthreads();                                                         // barrier 1 of 2: table ready
+    const int lane = threadIdx.x & 63;
+    const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);         // point row of this wave
+    const int ty = blockIdx.x / tiles_x;
+    const int tx = blockIdx.x - ty * tiles_x;
+    const int s0 = g.jm_lo - 1 + ty * (R - 1);
+    const int s = s0 + p;                                                    // this wave's step
+    int i = tx * 62 + lane;
+    const bool col_emit = lane >= 1 && lane <= 62 && i <= g.Nx;
+    if (i > g.Nx + 1) i = g.Nx + 1;
+    const double Rad = g.R;
+    const bool active_row = s <= g.jm_hi;                                    // rows past the band: idle waves
+    const long long col = (long long)(i + g.Hx - 1);
+    auto rowoff = [&](int j) -> long long { return col + (long long)g.sx * (j - g.jstart + g.Hy); };
+
+    // ---- phase 1: one point set per thread
+    Step4 q;
+    if (active_row) {
+        const bool fast = s >= 1 && s < g.Ny && absD(g.fplp90) <= 360.0;     // wave-uniform
+        if (fast) {
+            LaneConst lc;
+            const int iw = i < 1 ? i + g.Nx : (i > g.Nx ? i - g.Nx : i);
+            int i0 = iw - g.shift; if (i0 < 1) i0 += g.Nx;
+            lc.aslF = g.ti[0 * g.Nx + iw - 1]; lc.aclF = g.ti[1 * g.Nx + iw - 1];
+            lc.aslC = g.ti[2 * g.Nx + iw - 1]; lc.aclC = g.ti[3 * g.Nx + iw - 1];
+            lc.hemi = (i0 <= g.Nx / 2) ? -90.0 : 90.0;
+            points_fast2(g, lc, load_rowtab(g, s, s + 1), q, atab);
+        } else {
+            Step4 tmp; GridK gc = g; points_general(gc, i, s, s + 1, tmp); q = tmp;
+        }
+        // coordinates: rows p >= 1 emit CC/FC(s) and FF/CF(s+1); the first tile's apron row emits FF/CF(jm_lo)
+        if (col_emit) {
+            if (p >= 1 && s >= g.jm_lo) {
+                long long off = rowoff(s);
+                put<T, NT>(o, TPG_LAMBDA_FC, off, q.lam[0]); put<T, NT>(o, TPG_PHI_FC, off, q.phi[0]);
+                put<T, NT>(o, TPG_LAMBDA_CC, off, q.lam[1]); put<T, NT>(o, TPG_PHI_CC, off, q.phi[1]);
+            }
+            if ((p >= 1 || ty == 0) && s + 1 >= g.jm_lo && s + 1 <= g.jm_hi) {
+                long long off1 = rowoff(s + 1);
+                put<T, NT>(o, TPG_LAMBDA_FF, off1, q.lam[2]); put<T, NT>(o, TPG_PHI_FF, off1, q.phi[2]);
+                put<T, NT>(o, TPG_LAMBDA_CF, off1, q.lam[3]); put<T, NT>(o, TPG_PHI_CF, off1, q.phi[3]);
+            }
+        }
+        double (*L)[R][64] = lds.v;
+        L[L_FC + 0][p][lane] = q.lam[0]; L[L_FC + 1][p][lane] = q.a[0]; L[L_FC + 2][p][lane] = q.ca[0];
+        L[L_CC + 0][p][lane] = q.lam[1]; L[L_CC + 1][p][lane] = q.a[1]; L[L_CC + 2][p][lane] = q.ca[1];
+        L[L_CC + 3][p][lane] = q.X[0];   L[L_CC + 4][p][lane] = q.Y[0]; L[L_CC + 5][p][lane] = q.Z[0];
+        L[L_FF + 0][p][lane] = q.lam[2]; L[L_FF + 1][p][lane] = q.a[2]; L[L_FF + 2][p][lane] = q.ca[2];
+        L[L_FF + 3][p][lane] = q.X[1];   L[L_FF + 4][p][lane] = q.Y[1]; L[L_FF + 5][p][lane] = q.Z[1];
+        L[L_CF + 0][p][lane] = q.lam[3]; L[L_CF + 1][p][lane] = q.a[3]; L[L_CF + 2][p][lane] = q.ca[3];
+    }
+    __syncthreads();                                                         // barrier 2 of 2: point sets in LDS
+    if (!active_row || p == 0 || s < g.jm_lo || !col_emit) return;          // aprons and idle rows are done
+
+    // ---- phase 2: the cell (i, s) from own registers + LDS neighbours, loaded just in time so that the
+    //      live set stays under 128 VGPRs (4 waves/SIMD supply the ILP; batches of 2 suffice)
+    double (*L)[R][64] = lds.v;
+    const int pm = p - 1, le = lane + 1, lw = lane - 1;
+    const long long off = rowoff(s);
+
+    // 2 spherical quadrilaterals first (unit vectors only): Az_cc from FF points, Az_ff from CC points
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        V3 a, b, c, dd;
+        if (k == 0) {   // ffP = FF(i,s), ffEP = FF(i+1,s), ffE = FF(i+1,s+1), ff = FF(i,s+1)
+            a = V3{ L[L_FF + 3][pm][lane], L[L_FF + 4][pm][lane], L[L_FF + 5][pm][lane] };
+            b = V3{ L[L_FF + 3][pm][le], L[L_FF + 4][pm][le], L[L_FF + 5][pm][le] };
+            c = V3{ L[L_FF + 3][p][le], L[L_FF + 4][p][le], L[L_FF + 5][p][le] };
+            dd = V3{ q.X[1], q.Y[1], q.Z[1] };
+        } else {        // ccWP = CC(i-1,s-1), ccP = CC(i,s-1), cc = CC(i,s), ccW = CC(i-1,s)
+            a = V3{ L[L_CC + 3][pm][lw], L[L_CC + 4][pm][lw], L[L_CC + 5][pm][lw] };
+            b = V3{ L[L_CC + 3][pm][lane], L[L_CC + 4][pm][lane], L[L_CC + 5][pm][lane] };
+            c = V3{ q.X[0], q.Y[0], q.Z[0] };
+            dd = V3{ L[L_CC + 3][p][lw], L[L_CC + 4][p][lw], L[L_CC + 5][p][lw] };
+        }
+        double tt[4], at[4];
+        tt[0] = absD(dot3(a, cross3(b, c))) / (1 + dot3(a, b) + dot3(b, c) + dot3(a, c));
+        tt[1] = absD(dot3(a, cross3(b, dd))) / (1 + dot3(a, b) + dot3(b, dd) + dot3(a, dd));
+        tt[2] = absD(dot3(a, cross3(c, dd))) / (1 + dot3(a, c) + dot3(c, dd) + dot3(a, dd));
+        tt[3] = absD(dot3(b, cross3(c, dd))) / (1 + dot3(b, c) + dot3(c, dd) + dot3(b, dd));
+        if (__any(tpgb::atan_small_b<4>(tt, at))) tpgb::atan_b<4>(tt, at);
+        double A = 2 * at[0];
+        A += 2 * at[1];
+        A += 2 * at[2];
+        A += 2 * at[3];
+        put<T, NT>(o, k == 0 ? TPG_AZ_CC : TPG_AZ_FF, off, (A / 2) * (Rad * Rad));
+    }
+
+    // 8 haversines in pairs; operand e = (x point, y point), each {lam, a, ca}
+    //   0 dxcc(fcE,fc) 1 dxfc(cc,ccW) 2 dxcf(ffEP,ffP) 3 dxff(cfP,cfWP) 4 dycc(cf,cfP) 5 dyfc(ff,ffP) 6 dycf(cc,ccP) 7 dyff(fc,fcP)
+    auto ld = [&](int f, int pp, int ll) -> Nb { return Nb{ L[f + 0][pp][ll], L[f + 1][pp][ll], L[f + 2][pp][ll] }; };
+    const Nb own[4] = { Nb{ q.lam[0], q.a[0], q.ca[0] }, Nb{ q.lam[1], q.a[1], q.ca[1] },
+                        Nb{ q.lam[2], q.a[2], q.ca[2] }, Nb{ q.lam[3], q.a[3], q.ca[3] } };   // fc cc ff cf
+    double d[8];
+#pragma unroll
+    for (int hb = 0; hb < 8; hb += 2) {
+        Nb X[2], Y[2];
+        if (hb == 0)      { X[0] = ld(L_FC, p, le); Y[0] = own[0];            X[1] = own[1];            Y[1] = ld(L_CC, p, lw); }
+        else if (hb == 2) { X[0] = ld(L_FF, pm, le); Y[0] = ld(L_FF, pm, lane); X[1] = ld(L_CF, pm, lane); Y[1] = ld(L_CF, pm, lw); }
+        else if (hb == 4) { X[0] = own[3];           Y[0] = ld(L_CF, pm, lane); X[1] = own[2];            Y[1] = ld(L_FF, pm, lane); }
+        else              { X[0] = own[1];           Y[0] = ld(L_CC, pm, lane); X[1] = own[0];            Y[1] = ld(L_FC, pm, lane); }
+        double hp[2], hl[2], s1[2], s2[2], rm[2], as[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            double dl = (Y[e].lam - X[e].lam) * kDeg2Rad;
+            double dp = Y[e].a - X[e].a;
+            hp[e] = dp / 2; hl[e] = dl / 2;
+        }
+        if (tpgb::sin_small_b<2>(hp, s1)) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) s1[e] = sinD(hp[e]);
+        }
+        if (tpgb::sin_small_b<2>(hl, s2)) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) s2[e] = sinD(hl[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            double h = s1[e] * s1[e] + X[e].ca * Y[e].ca * (s2[e] * s2[e]);
+            const double r = sqrt(h);
+            const double mn = r < 1.0 ? r : 1.0;
+            rm[e] = r != r ? r : mn;
+        }
+        if (tpgb::asin_small_b<2>(rm, as)) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) as[e] = asinD(rm[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) d[hb + e] = 2 * (Rad * as[e]);
+    }
+    put<T, NT>(o, TPG_DX_CC, off, d[0]); put<T, NT>(o, TPG_DX_FC, off, d[1]);
+    put<T, NT>(o, TPG_DX_CF, off, d[2]); put<T, NT>(o, TPG_DX_FF, off, d[3]);
+    put<T, NT>(o, TPG_DY_CC, off, d[4]); put<T, NT>(o, TPG_DY_FC, off, d[5]);
+    put<T, NT>(o, TPG_DY_CF, off, d[6]); put<T, NT>(o, TPG_DY_FF, off, d[7]);
+    put<T, NT>(o, TPG_AZ_FC, off, d[5] * d[1]);
+    put<T, NT>(o, TPG_AZ_CF, off, d[6] * d[2]);
 }
 
 // ---- K2: halo cells of the 20 arrays ------------------------------------------------------------
@@ -763,7 +964,21 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
     const bool nt = getenv("TPG_BUILD_NT") ? atoi(getenv("TPG_BUILD_NT")) != 0 : true;
     const int variant = getenv("TPG_CELLS_VARIANT") ? atoi(getenv("TPG_CELLS_VARIANT")) : 2;
     const int strip_rows = getenv("TPG_CELLS_STRIP") ? atoi(getenv("TPG_CELLS_STRIP")) : 0;
-    if (variant == 1 || variant == 2) {
+    if (variant == 3) {
+        const int R = getenv("TPG_TILE_ROWS") ? atoi(getenv("TPG_TILE_ROWS")) : 8;      // 8 or 16 point rows per tile
+        const int tiles_x = (g.Nx + 61) / 62;
+        const int nrows = g.jm_hi - g.jm_lo + 1;
+        const int tiles_y = (nrows + (R - 1) - 1) / (R - 1);
+        dim3 gridt((unsigned)(tiles_x * tiles_y));
+        if (R == 16) {
+            if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, 16>), gridt, dim3(1024), 0, s, g, o, tiles_x);
+            else    hipLaunchKernelGGL((k_cells_tile<T, false, 16>), gridt, dim3(1024), 0, s, g, o, tiles_x);
+        } else {
+            if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, 8>), gridt, dim3(512), 0, s, g, o, tiles_x);
+            else    hipLaunchKernelGGL((k_cells_tile<T, false, 8>), gridt, dim3(512), 0, s, g, o, tiles_x);
+        }
+    }
+    else if (variant == 1 || variant == 2) {
         // strips sized so that the whole grid is (just under) one resident round of waves:
         // equal work per wave, no tail; short strips cost one extra point row each
         MarchArgs m;

@@ -30,7 +30,7 @@ def test_build_kernel_variants_agree(osg, gpu, knob, kw):
     kw = dict(kw)
     dtype = kw.pop("dtype", torch.float64)
     results = {}
-    for variant, nt, strip in ((2, 1, 0), (1, 1, 0), (0, 1, 0), (2, 0, 0), (2, 1, 7), (1, 1, 5)):
+    for variant, nt, strip in ((2, 1, 0), (1, 1, 0), (0, 1, 0), (3, 1, 0), (3, 0, 0), (2, 0, 0), (2, 1, 7), (1, 1, 5)):
         knob["TPG_CELLS_VARIANT"], knob["TPG_BUILD_NT"], knob["TPG_CELLS_STRIP"] = str(variant), str(nt), str(strip)
         g = osg.TripolarGrid(osg.GPU(0), dtype, **kw)
         results[(variant, nt, strip)] = {n: getattr(g, n).cpu().numpy() for n in osg._lib.ARRAY_NAMES}

@@ -14,6 +14,6 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     m = re.search(r"(k_[a-z_]+)", r["Kernel_Name"]); k = m.group(1) if m else "?"
     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k in ("k_cells_march", "k_cells_fast", "k_cells"):
+for k in ("k_cells_march", "k_cells_fast", "k_cells", "k_cells_tile"):
     if k in acc: print(k, {c: round(sum(v[1:]) / max(1, len(v[1:]))) for c, v in acc[k].items()})
 PY
