@@ -162,7 +162,8 @@ int tpg_fill_synthetic(void *field, uint64_t seed, double halo_sentinel,
 
 /* Validation hook (tests/test_gpu_math.py): evaluates one of the library's deterministic Float64
  * elementary functions (which = 0 sin, 1 cos, 2 sind, 3 cosd, 4 tand, 5 atan, 6 asin, 7 asinh, 8 sinh,
- * 9 cosh) or one of the straight-line batch forms used by the metric kernel (100 sin_small, 101 cos,
+ * 9 cosh; 20 sqrt_nr(x), 21 div_nr over pairs x = (a0, b0, a1, b1, ...): the unscaled square root and
+ * division of the metric kernel) or one of the straight-line batch forms used by the metric kernel (100 sin_small, 101 cos,
  * 102 atan, 103 atan_tab, 104 atan_small, 105 asin_small, 106 sind / 107 cosd of sincosd) on n device
  * doubles x -> y; rare[i] (int32) = 1 where a batch form reports "outside my fast domain".
  * No reference counterpart: these stand in for Julia Base / Distances arithmetic. */

@@ -170,10 +170,13 @@ template <int N> TPG_DEV void atan_tab_b(const double (&x)[N], double (&out)[N],
         const int id = (int)(ax[e] >= 0.6875) + (int)(ax[e] >= 1.1875) + (int)(ax[e] >= 2.4375);
         const AtanRow row = *reinterpret_cast<const AtanRow*>(tab + 6 * id);
         hi[e] = row.hi; lo[e] = row.lo;
-        const double axn = ax[e] < 0x1p1000 ? ax[e] : 0x1p1000;
+        const double axn = ax[e] > 0x1p1000 ? 0x1p1000 : ax[e];      // NaN stays NaN
         const double num = row.p * axn - row.q;
-        const double den = row.r + row.s * ax[e];
-        double q = num / den;
+        // den in [1, 1.5 * 2^1000] (axn, not ax: for ax >= 2^1000 the quotient -1/den is below 2^-999 either
+        // way, its square underflows to 0 and hi - ((t*0 - lo) - t) rounds to hi - (-lo) regardless), so the
+        // unscaled division is exact-equivalent; a NaN argument propagates through both forms
+        const double den = row.r + row.s * axn;
+        double q = tpgm::div_nr(num, den);
         asm volatile("" : "+v"(q));
         t[e] = direct[e] ? ax[e] : q;
     }
@@ -245,7 +248,9 @@ template <int N> TPG_DEV bool asin_small_b(const double (&x)[N], double (&out)[N
                                              q[e] = fmaD(t[e], q[e], 1.0); }
     TPG_UNROLL for (int e = 0; e < N; ++e) p[e] = fmaD(t[e], p[e], 1.66666666666666657415e-01);
     TPG_UNROLL for (int e = 0; e < N; ++e) p[e] = t[e] * p[e];
-    TPG_UNROLL for (int e = 0; e < N; ++e) out[e] = x[e] + x[e] * (p[e] / q[e]);
+    // q in (0.77, 1] for t < 0.25 and |p| <= 0.05 with p = 0 or |p| >= t/7 (t = x*x of a clamped sqrt: 0 or
+    // >= 1e-40 here), so the unscaled division is exact-equivalent; lanes with |x| >= 0.5 or NaN are `rare`
+    TPG_UNROLL for (int e = 0; e < N; ++e) out[e] = x[e] + x[e] * tpgm::div_nr(p[e], q[e]);
     return rare;
 }
 

@@ -244,6 +244,19 @@ __device__ __forceinline__ double quad_area(V3 a, V3 b, V3 c, V3 d)
     return A / 2;
 }
 
+// tan(E/2) of one spherical triangle through the unscaled division (tpgm::div_nr).  The denominator
+// 1 + a.b + b.c + a.c of unit vectors is 0 or at least ~1e-16 in magnitude and at most 4; a zero gives
+// NaN here (rcp(0) = inf), which the callers' atan_small_b reports as `rare`, and their fallback
+// recomputes the four tangents with IEEE `/` (tri_tan).
+__device__ __forceinline__ double tri_tan_nr(V3 a, V3 b, V3 c)
+{
+    return div_nr(absD(dot3(a, cross3(b, c))), 1 + dot3(a, b) + dot3(b, c) + dot3(a, c));
+}
+__device__ __forceinline__ double tri_tan(V3 a, V3 b, V3 c)
+{
+    return absD(dot3(a, cross3(b, c))) / (1 + dot3(a, b) + dot3(b, c) + dot3(a, c));
+}
+
 // NT = streaming store: the 20 output arrays (1 GB at 1/10 deg) are written once and not re-read by
 // this launch sequence; a plain store would park them as dirty lines in L2 / Infinity Cache and
 // the NEXT kernel on the stream (typically a halo fill) would pay for their eviction.
@@ -462,7 +475,7 @@ __device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc,
     double y[4] = { lc.aclF * shC, lc.aclC * shC, lc.aclF * shF, lc.aclC * shF };          // :68
     double q[4], rr[4], at1[4], at2[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt(y[k] * y[k] + x[k] * x[k]); }
+    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt_nr(y[k] * y[k] + x[k] * x[k]); }
     tpgb::atan_tab_b<4>(q, at1, atab);
     tpgb::atan_tab_b<4>(rr, at2, atab);
 #pragma unroll
@@ -492,7 +505,7 @@ __device__ __forceinline__ void points_fast2(const GridK& g, const LaneConst& lc
     double y[4] = { lc.aclF * shC, lc.aclC * shC, lc.aclF * shF, lc.aclC * shF };          // :68
     double q[4], rr[4], at1[4], at2[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt(y[k] * y[k] + x[k] * x[k]); }
+    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt_nr(y[k] * y[k] + x[k] * x[k]); }
 #pragma unroll
     for (int h = 0; h < 4; h += 2) {
         double qa[2] = { q[h], q[h + 1] }, ra[2] = { rr[h], rr[h + 1] }, o1[2], o2[2];
@@ -648,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 double h = s1[e] * s1[e] + xc_[hb + e] * yc_[hb + e] * (s2[e] * s2[e]);
-                const double r = sqrt(h);
+                const double r = sqrt_nr(h);              // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles)
                 const double mn = r < 1.0 ? r : 1.0;
                 rm[e] = r != r ? r : mn;
             }
@@ -668,11 +681,12 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
         for (int qd_ = 0; qd_ < 2; ++qd_) {
             const V3 a = qa[qd_], b = qb[qd_], c = qc[qd_], dd = qd[qd_];
             double tt[4], at[4];
-            tt[0] = absD(dot3(a, cross3(b, c))) / (1 + dot3(a, b) + dot3(b, c) + dot3(a, c));
-            tt[1] = absD(dot3(a, cross3(b, dd))) / (1 + dot3(a, b) + dot3(b, dd) + dot3(a, dd));
-            tt[2] = absD(dot3(a, cross3(c, dd))) / (1 + dot3(a, c) + dot3(c, dd) + dot3(a, dd));
-            tt[3] = absD(dot3(b, cross3(c, dd))) / (1 + dot3(b, c) + dot3(c, dd) + dot3(b, dd));
-            if (__any(tpgb::atan_small_b<4>(tt, at))) tpgb::atan_b<4>(tt, at);   // wave-uniform fallback
+            tt[0] = tri_tan_nr(a, b, c); tt[1] = tri_tan_nr(a, b, dd);
+            tt[2] = tri_tan_nr(a, c, dd); tt[3] = tri_tan_nr(b, c, dd);
+            if (__any(tpgb::atan_small_b<4>(tt, at))) {                 // wave-uniform fallback (large or degenerate triangles)
+                tt[0] = tri_tan(a, b, c); tt[1] = tri_tan(a, b, dd); tt[2] = tri_tan(a, c, dd); tt[3] = tri_tan(b, c, dd);
+                tpgb::atan_b<4>(tt, at);
+            }
             double A = 2 * at[0];
             A += 2 * at[1];
             A += 2 * at[2];
@@ -712,14 +726,19 @@ enum { L_FC = 0, L_CC = 3, L_FF = 9, L_CF = 15 };    // field bases: FC(lam,a,ca
 template <typename T, bool NT, int R>
 __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, int tiles_x)
 {
-    __shared__ __attribute__((aligned(16))) double atab[TPG_ATAN_TABLE_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double atabs[R][TPG_ATAN_TABLE_DOUBLES];
     __shared__ TileLds<R> lds;
-    tpgb::atan_table_init(atab, threadIdx.x);
-    __syncthreads();                                                         // barrier 1 of 2: table ready
     const int lane = threadIdx.x & 63;
     const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);         // point row of this wave
-    const int ty = blockIdx.x / tiles_x;
-    const int tx = blockIdx.x - ty * tiles_x;
+    // one copy of the atan interval table per wave: its load overlaps the lane's other table loads and
+    // needs no block barrier (LDS operations of one wave execute in order)
+    double* atab = atabs[p];
+    tpgb::atan_table_init(atab, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ty = blockIdx.y;
+    const int tx = blockIdx.x;
     const int s0 = g.jm_lo - 1 + ty * (R - 1);
     const int s = s0 + p;                                                    // this wave's step
     int i = tx * 62 + lane;
@@ -766,7 +785,7 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         L[L_FF + 3][p][lane] = q.X[1];   L[L_FF + 4][p][lane] = q.Y[1]; L[L_FF + 5][p][lane] = q.Z[1];
         L[L_CF + 0][p][lane] = q.lam[3]; L[L_CF + 1][p][lane] = q.a[3]; L[L_CF + 2][p][lane] = q.ca[3];
     }
-    __syncthreads();                                                         // barrier 2 of 2: point sets in LDS
+    __syncthreads();                                                         // the only barrier: point sets in LDS
     if (!active_row || p == 0 || s < g.jm_lo || !col_emit) return;          // aprons and idle rows are done
 
     // ---- phase 2: the cell (i, s) from own registers + LDS neighbours, loaded just in time so that the
@@ -791,11 +810,12 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
             dd = V3{ L[L_CC + 3][p][lw], L[L_CC + 4][p][lw], L[L_CC + 5][p][lw] };
         }
         double tt[4], at[4];
-        tt[0] = absD(dot3(a, cross3(b, c))) / (1 + dot3(a, b) + dot3(b, c) + dot3(a, c));
-        tt[1] = absD(dot3(a, cross3(b, dd))) / (1 + dot3(a, b) + dot3(b, dd) + dot3(a, dd));
-        tt[2] = absD(dot3(a, cross3(c, dd))) / (1 + dot3(a, c) + dot3(c, dd) + dot3(a, dd));
-        tt[3] = absD(dot3(b, cross3(c, dd))) / (1 + dot3(b, c) + dot3(c, dd) + dot3(b, dd));
-        if (__any(tpgb::atan_small_b<4>(tt, at))) tpgb::atan_b<4>(tt, at);
+        tt[0] = tri_tan_nr(a, b, c); tt[1] = tri_tan_nr(a, b, dd);
+        tt[2] = tri_tan_nr(a, c, dd); tt[3] = tri_tan_nr(b, c, dd);
+        if (__any(tpgb::atan_small_b<4>(tt, at))) {                 // wave-uniform fallback (large or degenerate triangles)
+            tt[0] = tri_tan(a, b, c); tt[1] = tri_tan(a, b, dd); tt[2] = tri_tan(a, c, dd); tt[3] = tri_tan(b, c, dd);
+            tpgb::atan_b<4>(tt, at);
+        }
         double A = 2 * at[0];
         A += 2 * at[1];
         A += 2 * at[2];
@@ -834,7 +854,7 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             double h = s1[e] * s1[e] + X[e].ca * Y[e].ca * (s2[e] * s2[e]);
-            const double r = sqrt(h);
+            const double r = sqrt_nr(h);              // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles)
             const double mn = r < 1.0 ? r : 1.0;
             rm[e] = r != r ? r : mn;
         }
@@ -969,7 +989,7 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
         const int tiles_x = (g.Nx + 61) / 62;
         const int nrows = g.jm_hi - g.jm_lo + 1;
         const int tiles_y = (nrows + (R - 1) - 1) / (R - 1);
-        dim3 gridt((unsigned)(tiles_x * tiles_y));
+        dim3 gridt((unsigned)tiles_x, (unsigned)tiles_y);
         if (R == 16) {
             if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, 16>), gridt, dim3(1024), 0, s, g, o, tiles_x);
             else    hipLaunchKernelGGL((k_cells_tile<T, false, 16>), gridt, dim3(1024), 0, s, g, o, tiles_x);

@@ -42,6 +42,40 @@ TPG_DEV double from_bits(uint64_t u) { return __longlong_as_double((long long)u)
 TPG_DEV int expo(double x) { return (int)((bits(x) >> 52) & 0x7ff); }
 TPG_DEV double fmaD(double a, double b, double c) { return __builtin_fma(a, b, c); }
 TPG_DEV double absD(double x) { return __builtin_fabs(x); }
+
+// a / b and sqrt(x) WITHOUT the range scaling and special-case fix-up of the compiler's expansions
+// (v_div_scale x2 + v_div_fixup; v_cmp/v_ldexp x2 + v_cmp_class/v_cndmask): the same Newton-Raphson
+// sequence on v_rcp_f64 / v_rsq_f64 that those expansions wrap, so the result is bit-identical to the
+// IEEE operation whenever the wrapper would not have acted:
+//   div_nr : b finite, 2^-1000 <= |b| <= 2^1000, a = 0 or a/b comfortably normal (callers document why)
+//   sqrt_nr: x = +-0, or 2^-767 <= x < inf  (x = 0 is handled by one select; NaN propagates)
+// 8 instead of 11 instructions per division, 13 instead of ~20 per square root -- ~6 % of the cell
+// kernel's VALU work.  Callers that cannot bound their operands keep `/` and sqrt().
+TPG_DEV double div_nr(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fmaD(-b, r, 1.0);
+    r = fmaD(r, e, r);
+    e = fmaD(-b, r, 1.0);
+    r = fmaD(r, e, r);
+    const double q = a * r;
+    e = fmaD(-b, q, a);
+    return fmaD(e, r, q);
+}
+TPG_DEV double sqrt_nr(double x)
+{
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r;
+    double h = r * 0.5;
+    const double e = fmaD(-h, g, 0.5);
+    g = fmaD(g, e, g);
+    double d = fmaD(-g, g, x);
+    h = fmaD(h, e, h);
+    g = fmaD(d, h, g);
+    d = fmaD(-g, g, x);
+    g = fmaD(d, h, g);
+    return x == 0.0 ? x : g;
+}
 TPG_DEV double csign(double mag, double sgn) { return __builtin_copysign(mag, sgn); }
 
 // exact fmod(x, 360): identity / one exact subtraction (Sterbenz) on the ranges the grid uses,

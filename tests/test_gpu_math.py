@@ -112,3 +112,25 @@ def test_batch_form_equals_scalar(osg, gpu, bid, sid, gen, domain):
     bad = inside & ~ok
     assert not bad.any(), f"{bad.sum()} mismatches inside the fast domain, e.g. x={x[bad][:3]!r} got={got[bad][:3]!r} want={want[bad][:3]!r}"
     assert np.array_equal(rare, ~grp), "rare flag must be raised exactly for groups with an outside argument"
+
+
+def test_unscaled_sqrt_and_division_are_ieee_on_their_domain(osg, gpu):
+    """csrc/tpg_math.hpp sqrt_nr / div_nr drop the range scaling and special-case fix-up of the compiler's
+    expansions; on the operand ranges the metric kernel feeds them they must return the correctly rounded
+    IEEE result (numpy's sqrt and / are correctly rounded)."""
+    r = np.random.default_rng(77)
+    x = np.concatenate([r.uniform(0, 2, N), 10.0 ** r.uniform(-200, 200, N), np.array([0.0, 1.0, 4.0, 2.0 ** -700, 1e-34, 1e300])])
+    got, _ = probe(osg, gpu, 20, x)
+    assert same_bits(got, np.sqrt(x)).all()
+    got, _ = probe(osg, gpu, 20, np.array([np.nan, -1.0]))
+    assert np.isnan(got).all()
+    # divisions of the kernel: triangle tangents (|a| <= 2 incl. 0 and tiny, 1e-16 <= |b| <= 4), asin's p / q
+    # (q in (0.7, 1]), atan's reduced argument (1 <= b <= 1.5 * 2^1000)
+    a = np.concatenate([r.uniform(-2, 2, N), 10.0 ** r.uniform(-60, 0.3, N), np.zeros(1000), r.uniform(-1, 1, N), -np.ones(N // 2)])
+    b = np.concatenate([r.uniform(1e-3, 4, N) * r.choice([-1, 1], N), 10.0 ** r.uniform(-16, 0.6, N), r.uniform(0.5, 4, 1000),
+                        r.uniform(0.7, 1.0, N), np.concatenate([10.0 ** r.uniform(0, 300, N // 2 - 3), np.array([2.0 ** 1000, 1.5 * 2.0 ** 1000, 1.0])])])
+    xy = np.empty(2 * a.size)
+    xy[0::2], xy[1::2] = a, b
+    got, _ = probe(osg, gpu, 21, xy)
+    want = a / b
+    assert same_bits(got[0::2], want).all() and same_bits(got[1::2], want).all()
