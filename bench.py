@@ -194,8 +194,9 @@ def main():
     main_stream = torch.cuda.current_stream(dev)
     side_stream = torch.cuda.Stream(dev) if world > 1 else None
     if world > 1:
-        # the build shares the GPU with RCCL's send/recv workgroups: plan its single resident round
-        # for 90 % of the wave slots (see TPG_CELLS_CAPACITY in csrc/tpg_grid.hip)
+        # the build shares the GPU with RCCL's send/recv workgroups.  The default tile kernel is made of
+        # ~15 000 short blocks and simply yields them a few wave slots; the marching kernels
+        # (TPG_CELLS_VARIANT=2/1) plan ONE resident round and are told to plan it for 90 % of the slots
         os.environ.setdefault("TPG_CELLS_CAPACITY", "0.9")
 
     def step_overlapped(marks=None, zev=None):
@@ -303,13 +304,13 @@ def main():
                                 "achieved": zbytes / (t_zip * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": zbytes / (t_zip * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                                 "algorithmic_bytes_per_launch": zbytes, "launch_ms": t_zip}
-        flops = 3500.0 * NX * NY                                    # ~3.5 kflop FP64 per cell
+        flops = 2333.0 * NX * (jend - jstart + 1)                           # FP64 add/mul/fma (fma = 2) per cell, PMC-counted
         line["roofline_precompute"] = {
-            "kernel": "tpg_build_grid (k_tables + k_cells_fast + k_halos + k_south)", "bound": "hbm",
+            "kernel": "tpg_build_grid (k_tables + k_cells_tile + k_halos + k_south)", "bound": "hbm",
             "achieved": 160.0 * band_cells / (t_build * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
             "algorithmic_bytes_per_launch": 160 * band_cells,
-            "note": "FP64-transcendental bound in practice: ~%.1f TFLOP/s of the %.1f TFLOP/s vector FP64 peak at ~3.5 kflop/cell"
+            "note": "FP64-issue bound in practice (VALU busy 88 %%): ~%.1f TFLOP/s of the %.1f TFLOP/s vector FP64 peak at 2.33 kflop/cell (PMC count)"
                     % (flops / (t_build * 1e-3) / 1e12, FP64_VALU_PEAK_TFLOPS)}
         if world == 1 and not args.no_cpu_baseline:
             threads = 1

@@ -12,16 +12,21 @@
 //                    staggered locations of the cell and of its stencil neighbours THROUGH the halo
 //                    index maps (periodic x, zipper fold, row-Ny substitution, zero south halo),
 //                    then the 8 haversine edge lengths, 2 spherical quadrilateral areas and 2
-//                    product areas; stores 8 + 12 values.  Three forms with identical arithmetic
+//                    product areas; stores 8 + 12 values.  Four forms with identical arithmetic
 //                    (tests/test_gpu_variants.py), selected by TPG_CELLS_VARIANT:
-//                      2  k_cells_fast   DEFAULT.  Waves of 62 columns march north over a strip of
-//                                        rows; each staggered point is evaluated once, kept in
-//                                        registers, shared with the neighbour lanes by shuffles;
-//                                        transcendentals as straight-line batches (tpg_batch.hpp).
+//                      3  k_cells_tile   DEFAULT.  A block of 8 waves evaluates 8 point rows x 64
+//                                        columns once (one point set per thread), parks them in LDS
+//                                        and, after one barrier, every thread computes its cell from
+//                                        its own registers + LDS neighbours.  <= 128 VGPRs: 4
+//                                        waves/SIMD; transcendentals as straight-line batches
+//                                        (tpg_batch.hpp).
+//                      2  k_cells_fast   waves of 62 columns march north over a strip of rows; the
+//                                        point sets of two rows stay in registers (256 VGPRs, 2
+//                                        waves/SIMD) and reach the neighbour lanes by shuffles.
 //                      1  k_cells_march  same marching scheme on the scalar functions; also the
 //                                        path for |first_pole_longitude + 90| > 360 inside (2).
 //                      0  k_cells        one thread per cell, everything recomputed: the simple
-//                                        reference form the other two are checked against.
+//                                        reference form the others are checked against.
 //   K2 halos       : compact pass over halo cells only (x-halo columns, north fold rows, zero
 //                    south rows of the coordinates, row-Ny substitution of the y-Center metrics).
 //   K3 south       : lat-lon continuation rows j = 1-Hy..1 of the 12 metrics (south rank only).
@@ -977,12 +982,13 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
 {
     dim3 grid1(((g.Nx + 255) / 256) * (g.jm_hi - g.jm_lo + 1));
     // tuning / cross-check knobs, read per call (tests/test_gpu_variants.py switches them in-process):
-    //   TPG_CELLS_VARIANT 2 = k_cells_fast (default), 1 = k_cells_march, 0 = k_cells (thread per cell)
+    //   TPG_CELLS_VARIANT 3 = k_cells_tile (default), 2 = k_cells_fast, 1 = k_cells_march, 0 = k_cells (thread per cell)
     //   TPG_BUILD_NT      1 = streaming stores (default), 0 = plain stores
     //   TPG_CELLS_STRIP   rows per strip of the marching kernels (default: one resident round)
     //   TPG_CELLS_CAPACITY fraction of the wave slots that round may assume (default 1)
     const bool nt = getenv("TPG_BUILD_NT") ? atoi(getenv("TPG_BUILD_NT")) != 0 : true;
-    const int variant = getenv("TPG_CELLS_VARIANT") ? atoi(getenv("TPG_CELLS_VARIANT")) : 2;
+    int variant = getenv("TPG_CELLS_VARIANT") ? atoi(getenv("TPG_CELLS_VARIANT")) : 3;
+    if (variant == 3 && (g.jm_hi - g.jm_lo + 1 + 6) / 7 > 65535) variant = 2;     // tile rows ride on gridDim.y
     const int strip_rows = getenv("TPG_CELLS_STRIP") ? atoi(getenv("TPG_CELLS_STRIP")) : 0;
     if (variant == 3) {
         const int R = getenv("TPG_TILE_ROWS") ? atoi(getenv("TPG_TILE_ROWS")) : 8;      // 8 or 16 point rows per tile

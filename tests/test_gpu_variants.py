@@ -1,6 +1,5 @@
-"""Every kernel variant kept in the library (the simple thread-per-cell build kernel, the marching
-kernel that also serves as the general fallback, the fast default; the zipper's row / column /
-streaming forms) must produce identical bits: they differ only in how the same arithmetic is
+"""Every kernel variant kept in the library (the simple thread-per-cell build kernel, the two marching
+kernels, the LDS-tile default; the zipper's row / column / streaming forms) must produce identical bits: they differ only in how the same arithmetic is
 scheduled.  The TPG_* knobs are read per call."""
 import os
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc2.sh <tag> <counters...>   (env passes through to bench.py)
+# usage: [PMC_KERNELS=k_a,k_b] tools/pmc2.sh <tag> <counters...>   (env passes through to bench.py)
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/pmc2_$TAG; rm -rf "$OUT"; mkdir -p "$OUT"
@@ -14,6 +14,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     m = re.search(r"(k_[a-z_]+)", r["Kernel_Name"]); k = m.group(1) if m else "?"
     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k in ("k_cells_march", "k_cells_fast", "k_cells", "k_cells_tile"):
+import os
+want = os.environ.get("PMC_KERNELS", "k_cells_march,k_cells_fast,k_cells,k_cells_tile").split(",")
+for k in want:
     if k in acc: print(k, {c: round(sum(v[1:]) / max(1, len(v[1:]))) for c, v in acc[k].items()})
 PY
