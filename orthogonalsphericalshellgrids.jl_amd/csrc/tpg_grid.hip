@@ -893,9 +893,10 @@ __device__ __forceinline__ void array_loc(int q, int& xl, int& yl)
 struct HaloRegions {
     int nA;   // x-halo columns of evaluated rows: (jm_hi-jm_lo+1) * 2Hx
     int nB;   // north rows j = Ny+1..Ny+Hy (north rank): Hy * sx
-    int nC;   // south rows j < 1 present in the band: nsouth * sx
+    int nC;   // south rows j < 1 present in the band (+ row 1 when K3 is merged): (nsouth + row1) * sx
     int nD;   // row-Ny substitution cells i = Nx/2+1..Nx (north rank): Nx/2
     int nsouth;
+    int merged_south;   // 1: this launch also writes the lat-lon continuation rows j <= 1 of the 12 metrics (K3)
 };
 
 template <typename T>
@@ -915,14 +916,20 @@ __global__ __launch_bounds__(256) void k_halos(GridK g, OutPtrs o, HaloRegions h
         int r = t / (2 * g.Hx), c = t - r * 2 * g.Hx;
         j = g.jm_lo + r;
         i = c < g.Hx ? 1 - g.Hx + c : g.Nx + 1 + (c - g.Hx);
+        if (h.merged_south && !is_coord && j <= 1) return;   // row 1 of the metrics is written whole by region C
     } else if ((t -= h.nA) < h.nB) {
         int r = t / g.sx, c = t - r * g.sx;
         j = g.Ny + 1 + r; i = 1 - g.Hx + c;
     } else if ((t -= h.nB) < h.nC) {
         int r = t / g.sx, c = t - r * g.sx;
         j = 1 - h.nsouth + r; i = 1 - g.Hx + c;
-        if (is_coord) A[at(i, j)] = (T)0;        // south = nothing: halos stay zero (tripolar_grid.jl:148)
-        return;                                  // metrics: rows j <= 1 belong to K3
+        if (is_coord) { if (j < 1) A[at(i, j)] = (T)0; return; }   // south = nothing: halos stay zero (tripolar_grid.jl:148)
+        if (!h.merged_south) return;             // metrics: rows j <= 1 belong to K3
+        // continue_south! (tripolar_grid.jl:287-300,336-357): Dx and Az by y-location, one Dy for all
+        const int n = g.Hy + 1, rt = j - (1 - g.Hy);
+        const int col = (q >= TPG_DY_CC && q <= TPG_DY_FF) ? 4 : ((q >= TPG_AZ_CC ? 2 : 0) + (yl == TPG_FACE ? 1 : 0));
+        A[at(i, j)] = (T)g.ts[col * n + rt];
+        return;
     } else if ((t -= h.nC) < h.nD) {
         if (is_coord || yl != TPG_CENTER) return; // coordinates were evaluated through the substitution already
         i = g.Nx / 2 + 1 + t; j = g.Ny;
@@ -1048,12 +1055,18 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
     else         hipLaunchKernelGGL((k_cells<T, false>), grid1, dim3(256), 0, s, g, o);
     int rc = tpg::launch_status("k_cells");
     if (rc) return rc;
-    int nh = h.nA + h.nB + h.nC + h.nD;
+    // K3 rides in the K2 launch unless the grid is so short that a north-fold source row or the row-Ny
+    // substitution could be a continuation row (then K3 must run after K2, as in the reference's order)
+    HaloRegions hm = h;
+    const bool south_in_band = g.jstart - g.Hy <= 1;
+    hm.merged_south = (south_in_band && g.Ny > 2 * g.Hy + 2) ? 1 : 0;
+    if (hm.merged_south) hm.nC = (h.nsouth + 1) * g.sx;
+    int nh = hm.nA + hm.nB + hm.nC + hm.nD;
     if (nh > 0) {
-        hipLaunchKernelGGL(k_halos<T>, dim3((nh + 255) / 256, TPG_NUM_ARRAYS), dim3(256), 0, s, g, o, h);
+        hipLaunchKernelGGL(k_halos<T>, dim3((nh + 255) / 256, TPG_NUM_ARRAYS), dim3(256), 0, s, g, o, hm);
         if ((rc = tpg::launch_status("k_halos"))) return rc;
     }
-    if (g.jstart - g.Hy <= 1) {
+    if (south_in_band && !hm.merged_south) {
         hipLaunchKernelGGL(k_south<T>, dim3((g.sx + 255) / 256, g.Hy + 1), dim3(256), 0, s, g, o);
         if ((rc = tpg::launch_status("k_south"))) return rc;
     }
