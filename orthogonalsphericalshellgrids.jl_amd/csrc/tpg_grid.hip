@@ -998,18 +998,13 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
     if (variant == 3 && (g.jm_hi - g.jm_lo + 1 + 6) / 7 > 65535) variant = 2;     // tile rows ride on gridDim.y
     const int strip_rows = getenv("TPG_CELLS_STRIP") ? atoi(getenv("TPG_CELLS_STRIP")) : 0;
     if (variant == 3) {
-        const int R = getenv("TPG_TILE_ROWS") ? atoi(getenv("TPG_TILE_ROWS")) : 8;      // 8 or 16 point rows per tile
+        constexpr int R = 8;                                   // point rows per tile (16 = one block per CU: measured 25 % slower)
         const int tiles_x = (g.Nx + 61) / 62;
         const int nrows = g.jm_hi - g.jm_lo + 1;
         const int tiles_y = (nrows + (R - 1) - 1) / (R - 1);
         dim3 gridt((unsigned)tiles_x, (unsigned)tiles_y);
-        if (R == 16) {
-            if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, 16>), gridt, dim3(1024), 0, s, g, o, tiles_x);
-            else    hipLaunchKernelGGL((k_cells_tile<T, false, 16>), gridt, dim3(1024), 0, s, g, o, tiles_x);
-        } else {
-            if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, 8>), gridt, dim3(512), 0, s, g, o, tiles_x);
-            else    hipLaunchKernelGGL((k_cells_tile<T, false, 8>), gridt, dim3(512), 0, s, g, o, tiles_x);
-        }
+        if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x);
+        else    hipLaunchKernelGGL((k_cells_tile<T, false, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x);
     }
     else if (variant == 1 || variant == 2) {
         // strips sized so that the whole grid is (just under) one resident round of waves:
