@@ -131,7 +131,10 @@ int tpg_periodic_x_fill(void *const fields[], int nfields,
 
 /* fill_halo_regions!(field) on a (Periodic, RightConnected, *) tripolar field: zipper on
  * k = 1..Nz if `north_is_zipper` (serial grid, or last rank: src/distributed_tripolar_grid.jl:
- * 143-147,177-185), then periodic x. */
+ * 143-147,177-185), then periodic x.  Small fields (2-D free-surface / barotropic fields: fewer than 2^20
+ * written cells per call) take ONE fused launch in which every written cell is computed from original
+ * interior values through the composed index map; results are identical to the two-launch sequence.
+ * TPG_FILL_FUSED=0 disables, =1 forces the fused form wherever Nx >= 2Hx+2 and Ny >= 2Hy+2. */
 int tpg_fill_halo_regions(void *const fields[], int nfields,
                           const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                           int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,

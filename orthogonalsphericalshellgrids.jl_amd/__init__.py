@@ -14,8 +14,8 @@ from .grids import (CPU, GPU, Distributed, Partition, OrthogonalSphericalShellGr
                     TripolarGrid, is_tripolar, local_row_range, local_sizes, reconstruct_global_grid,
                     with_halo, x_domain, y_domain, RightConnected, FullyConnected, Bounded,
                     PeriodicTopology)
-from .fields import (CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions,
-                     interior, set_)
+from .fields import (CenterField, Field, HaloFillPlan, XFaceField, YFaceField, ZFaceField, fill_halo_regions,
+                     halo_fill_plan, interior, set_)
 from .distributed import exchange_plan, exchange_y_halos, torch_distributed_transport
 
 __all__ = ["TripolarGrid", "ZipperBoundaryCondition"]

@@ -264,6 +264,62 @@ __global__ __launch_bounds__(256) void k_periodic_x_vec(PtrTable pt, PerArgs a, 
     c[hxc + nxc + v] = e;
 }
 
+// ---- fused fill for small fields: zipper + periodic x in ONE launch ------------------------------
+// A 2-D field (free surface, barotropic U, V: a few hundred KB) is filled in a few microseconds, so the
+// two-launch sequence is pure launch latency -- and a split-explicit free surface does 3 such fills per
+// substep, ~30 substeps per baroclinic step.  Every cell the sequence
+// "fold north (zipper_boundary_condition.jl:70-138), then periodic west/east" writes is a function of
+// ORIGINAL interior values only, so the two maps compose and one thread per written cell can apply
+// them directly, race-free:
+//   north halo row Ny+dj, any column i (corners included; iw = i wrapped into 1..Nx):
+//        c[i, Ny+dj] = s' c[i'(iw), Ny-dj (+1 for y-Face)]
+//   row Ny of y-Center fields, iw > Nx/2 (interior cell: the substitution; halo cell: its periodic copy):
+//        c[i, Ny]    = s' c[i'(iw), Ny]
+//   west / east halo cell of any other row (and of the z-halo levels, which the zipper skips):
+//        c[i, j]     = c[iw, j]
+// with i' = Nx-iw+1 (x-Center) or Nx-iw+2 (x-Face; iw = 1 wraps to i' = 1 with s' = |s|).  The only cell
+// that is both read and written, the x-Face self-map i = Nx/2+1 of row Ny, is read by its own thread as
+// long as it is no periodic source, i.e. Nx >= 2 Hx + 2; fold sources stay clear of written rows for
+// Ny >= 2 Hy + 2.  Other geometries take the two-launch path.
+struct FusedArgs { int Nx, Ny, Hx, Hy, Hz, Nz, sx, sy; long long plane; int per_level; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill_fused(FieldTable ft, FusedArgs a)
+{
+    const int f = blockIdx.y;
+    int item = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nlev = a.Nz + 2 * a.Hz;
+    if (item >= a.per_level * nlev) return;
+    const int lev = item / a.per_level;
+    item -= lev * a.per_level;
+    const int xl = ft.xloc[f], yl = ft.yloc[f];
+    int sgn = ft.sign[f];
+    T* c = static_cast<T*>(ft.ptr[f]) + a.plane * lev;
+    const bool zipped = lev >= a.Hz && lev < a.Hz + a.Nz;
+    // candidate cells of a level: (Hy+1) full rows from row Ny up, then the 2 Hx halo columns of the rows below
+    int ii, jj;
+    const int top = (a.Hy + 1) * a.sx;
+    if (item < top) { jj = a.Ny + a.Hy - 1 + item / a.sx; ii = item % a.sx; }
+    else { item -= top; jj = item / (2 * a.Hx); const int h = item - jj * 2 * a.Hx; ii = h < a.Hx ? h : a.Nx + h; }
+    const int i = ii - a.Hx + 1, j = jj - a.Hy + 1;
+    const int iw = i < 1 ? i + a.Nx : (i > a.Nx ? i - a.Nx : i);
+    int ip = (xl == TPG_FACE) ? a.Nx - iw + 2 : a.Nx - iw + 1;
+    if (ip > a.Nx) { sgn = sgn < 0 ? -sgn : sgn; ip -= a.Nx; }
+    T v;
+    if (zipped && j > a.Ny) {
+        const int dj = j - a.Ny;
+        const int jsrc = (yl == TPG_FACE) ? a.Ny - dj + 1 : a.Ny - dj;
+        v = (T)sgn * c[(long long)a.sx * (jsrc + a.Hy - 1) + (ip + a.Hx - 1)];
+    } else if (zipped && j == a.Ny && yl == TPG_CENTER && iw > a.Nx / 2) {
+        v = (T)sgn * c[(long long)a.sx * jj + (ip + a.Hx - 1)];
+    } else if (i != iw) {
+        v = c[(long long)a.sx * jj + (iw + a.Hx - 1)];
+    } else {
+        return;                                   // interior cell that no fill touches
+    }
+    c[(long long)a.sx * jj + ii] = v;
+}
+
 // ---- latitude-band message pack / unpack --------------------------------------------------------
 struct PackArgs { int sx, sy, nlev, Hy, row0; long long plane; int nfields; int chunk_elems; };
 
@@ -511,6 +567,38 @@ int tpg_fill_halo_regions(void* const fields[], int nfields, const int8_t xloc[]
                           int north_is_zipper, int ft, void* stream)
 {
     int rc = TPG_OK;
+    // small fields: one fused launch (k_fill_fused); TPG_FILL_FUSED=0 never, =1 whenever the geometry allows
+    const char* knob = getenv("TPG_FILL_FUSED");
+    const int mode = knob ? atoi(knob) : -1;
+    if (north_is_zipper && mode != 0 && Hx > 0 && Hy > 0 && Nx >= 2 * Hx + 2 && Ny >= 2 * Hy + 2) {
+        const long long per_level = (long long)(Hy + 1) * (Nx + 2 * Hx) + 2ll * Hx * (Ny + Hy - 1);
+        const long long items = per_level * (Nz + 2 * Hz);
+        if (items < (1ll << 31) && (mode == 1 || items * nfields <= (1ll << 20))) {
+            if ((rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft))) return rc;
+            if ((rc = check_fields(fields, nfields))) return rc;
+            if (!xloc || !yloc || !sign) { tpg::set_error("null location/sign table"); return TPG_ERR_INVALID_ARGUMENT; }
+            for (int f = 0; f < nfields; ++f)
+                if ((xloc[f] != TPG_CENTER && xloc[f] != TPG_FACE) || (yloc[f] != TPG_CENTER && yloc[f] != TPG_FACE)) {
+                    tpg::set_error("field %d: no zipper method for location (%d,%d)", f, xloc[f], yloc[f]);
+                    return TPG_ERR_INVALID_ARGUMENT;
+                }
+            Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
+            FusedArgs a{ Nx, Ny, Hx, Hy, Hz, Nz, g.sx, g.sy, (long long)g.sx * g.sy, (int)per_level };
+            hipStream_t s = tpg::as_stream(stream);
+            for (int f0 = 0; f0 < nfields; f0 += TPG_MAX_FIELDS) {
+                const int n = nfields - f0 < TPG_MAX_FIELDS ? nfields - f0 : TPG_MAX_FIELDS;
+                FieldTable t;
+                t.nfields = n;
+                for (int f = 0; f < n; ++f) { t.ptr[f] = fields[f0 + f]; t.xloc[f] = xloc[f0 + f]; t.yloc[f] = yloc[f0 + f]; t.sign[f] = sign[f0 + f]; t.item0[f] = 0; }
+                t.item0[n] = 0;
+                dim3 grid((unsigned)((items + 255) / 256), (unsigned)n);
+                if (ft == TPG_F64) hipLaunchKernelGGL(k_fill_fused<double>, grid, dim3(256), 0, s, t, a);
+                else               hipLaunchKernelGGL(k_fill_fused<float>, grid, dim3(256), 0, s, t, a);
+                if ((rc = tpg::launch_status("k_fill_fused"))) return rc;
+            }
+            return TPG_OK;
+        }
+    }
     if (north_is_zipper)
         rc = tpg_zipper_fill(fields, nfields, xloc, yloc, sign, Nx, Ny, Nz, Hx, Hy, Hz, 1, Nz, ft, stream);
     if (rc) return rc;

@@ -1,6 +1,7 @@
 """GPU parity of the Zipper halo fill (tpg_zipper_fill / tpg_fill_halo_regions) against the
 oracle: bit-exact on the whole padded array (integer index map + sign)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -73,9 +74,23 @@ GEOMS = [((10, 10, 1), (4, 4, 4)), ((60, 30, 3), (4, 4, 4)), ((62, 31, 2), (3, 2
          ((3600, 24, 2), (4, 4, 4))]     # full 1/10 degree rows
 
 
+@pytest.fixture
+def fused_knob():
+    saved = os.environ.get("TPG_FILL_FUSED")
+    yield os.environ
+    if saved is None:
+        os.environ.pop("TPG_FILL_FUSED", None)
+    else:
+        os.environ["TPG_FILL_FUSED"] = saved
+
+
+@pytest.mark.parametrize("fused", ["0", "1"], ids=["two-launch", "fused"])
 @pytest.mark.parametrize("size,halo", GEOMS, ids=[f"{s}-{h}" for s, h in GEOMS])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_fill_halo_regions_parity(osg, oracle, gpu, size, halo, dtype):
+def test_fill_halo_regions_parity(osg, oracle, gpu, fused_knob, size, halo, dtype, fused):
+    """zipper -> periodic x as two launches, and as the single fused launch small fields take by default
+    (geometries the fused kernel does not cover -- Nx < 2 Hx + 2, Ny < 2 Hy + 2 -- fall back by themselves)"""
+    fused_knob["TPG_FILL_FUSED"] = fused
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     grid = osg.TripolarGrid(osg.GPU(0), tdt, size=size, halo=halo)
     specs = [(xl, yl, sg) for xl, yl in LOCS for sg in (1, -1)]
@@ -223,3 +238,51 @@ def test_randomised_geometries_against_the_oracle(osg, oracle, gpu):
         if Hy > 0 and kcount > 0:
             oracle.zipper_fill(h, xl, yl, sgn, (Nx, Ny, Nz), (Hx, Hy, Hz), kstart, kcount)
         assert np.array_equal(d.cpu().numpy(), h), (trial, Nx, Ny, Nz, Hx, Hy, Hz, xl, yl, sgn, kstart, kcount)
+
+
+def test_fused_fill_randomised_against_the_oracle(osg, oracle, gpu, fused_knob):
+    """60 random geometries through tpg_fill_halo_regions with the fused kernel forced on (and the automatic
+    choice): whole padded array bit-identical to the oracle's zipper -> periodic x sequence"""
+    lib = osg._lib.lib()
+    rng = np.random.default_rng(4242)
+    for trial in range(60):
+        fused_knob["TPG_FILL_FUSED"] = "1"
+        if trial % 3 == 2:
+            fused_knob.pop("TPG_FILL_FUSED")
+        Nx = int(rng.choice([4, 6, 10, 12, 14, 16, 30, 64, 66, 128, 130, 258]))
+        Ny = int(rng.integers(2, 30))
+        Nz = int(rng.integers(1, 4))
+        Hx = int(rng.integers(1, min(Nx, 6) + 1))
+        Hy = int(rng.integers(1, min(Ny, 9) + 1))
+        Hz = int(rng.integers(0, 3))
+        nf = int(rng.integers(1, 5))
+        dt, tdt, ft = ((np.float64, torch.float64, 1), (np.float32, torch.float32, 0))[trial % 2]
+        specs = [(int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([1, -1, 2]))) for _ in range(nf)]
+        hosts = [rng.uniform(-1, 1, (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)).astype(dt) for _ in specs]
+        devs = [torch.from_numpy(h).to(gpu) for h in hosts]
+        xl = (C.c_int8 * nf)(*[s[0] for s in specs]); yl = (C.c_int8 * nf)(*[s[1] for s in specs]); sg = (C.c_int32 * nf)(*[s[2] for s in specs])
+        rc = lib.tpg_fill_halo_regions(osg._lib.ptr_table(devs), nf, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, 1, ft, None)
+        assert rc == 0, (trial, lib.tpg_last_error())
+        torch.cuda.synchronize()
+        for d, h, (x, y, sgn) in zip(devs, hosts, specs):
+            oracle.fill_halo_regions(h, x, y, sgn, (Nx, Ny, Nz), (Hx, Hy, Hz))
+            assert np.array_equal(d.cpu().numpy(), h), (trial, Nx, Ny, Nz, Hx, Hy, Hz, x, y, sgn)
+
+
+def test_halo_fill_plan_equals_fill_halo_regions(osg, oracle, gpu):
+    """a HaloFillPlan built once and called repeatedly gives what fill_halo_regions! gives each time
+    (the self-mapped x-Face cell of row Ny flips sign on every fill of a -1 field, as in the reference)"""
+    size, halo = (60, 30, 2), (4, 4, 2)
+    grid = osg.TripolarGrid(size=size, halo=halo)
+    rng = np.random.default_rng(21)
+    u, c = osg.XFaceField(grid), osg.CenterField(grid)
+    eta = osg.Field((osg.Center, osg.Center, None), grid)
+    hosts = []
+    for f in (u, c, eta):
+        h = rng.uniform(-1, 1, tuple(f.data.shape)); f.data.copy_(torch.from_numpy(h)); hosts.append(h)
+    plan = osg.halo_fill_plan((u, c, eta))
+    for _ in range(3):
+        plan()
+        for f, h, (xl, yl, sg) in zip((u, c, eta), hosts, ((1, 0, -1), (0, 0, 1), (0, 0, 1))):
+            oracle.fill_halo_regions(h, xl, yl, sg, (size[0], size[1], f.Nz), (halo[0], halo[1], f.Hz))
+            assert np.array_equal(f.data.cpu().numpy(), h), f.loc

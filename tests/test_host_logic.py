@@ -82,3 +82,12 @@ def test_unicode_property_aliases(osg):
     assert _UNICODE_ALIASES[unicodedata.normalize("NFKC", "φᶠᶜᵃ")] == "phi_fc"
     assert _UNICODE_ALIASES[unicodedata.normalize("NFKC", "Azᶜᶠᵃ")] == "az_cf"
     assert len(_UNICODE_ALIASES) == 20
+
+
+def test_halo_fill_plan_is_exported_and_validates_fields():
+    """HaloFillPlan (the reusable form of fill_halo_regions!) is part of the host surface; building one
+    touches no device memory, so its validation can be checked on CPU"""
+    import orthogonalsphericalshellgrids.jl_amd as osg
+    assert callable(osg.halo_fill_plan) and osg.HaloFillPlan is not None
+    plan = osg.halo_fill_plan([])
+    assert plan() is None and plan.fields == []
