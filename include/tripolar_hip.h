@@ -21,6 +21,15 @@
  *      3-D  c[i,j,k] at  (i+Hx-1) + (Nx+2Hx) * ((j+Hy-1) + (Ny+2Hy) * (k+Hz-1))
  *    i.e. exactly the `parent` of Oceananigans' OffsetArrays.
  *  - element type selected by `ft`: TPG_F32 or TPG_F64.
+ *
+ * Tuning / cross-check knobs (environment, read per call; every setting gives identical results --
+ * tests/test_gpu_variants.py -- and none is needed in production):
+ *    TPG_CELLS_VARIANT   cell kernel of tpg_build_grid: 3 LDS tile (default), 2 / 1 marching waves,
+ *                        0 thread per cell
+ *    TPG_BUILD_NT        1 streaming stores in tpg_build_grid (default), 0 plain stores
+ *    TPG_CELLS_STRIP, TPG_CELLS_CAPACITY   strip sizing of the marching variants
+ *    TPG_ZIPPER_VARIANT  0..7: row / column work items, streaming loads / stores (default 3)
+ *    TPG_FILL_FUSED      0 never / 1 always (where valid) use the fused small-field fill
  */
 #ifndef TRIPOLAR_HIP_H
 #define TRIPOLAR_HIP_H
