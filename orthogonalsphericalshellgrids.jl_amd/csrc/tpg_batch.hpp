@@ -257,13 +257,20 @@ template <int N> TPG_DEV bool asin_small_b(const double (&x)[N], double (&out)[N
 // sind / cosd pairs for |x| < 360 (longitudes in [0,360), latitudes in [-90,90]: rem(x,360) = x)
 template <int N> TPG_DEV void sincosd_b(const double (&x)[N], double (&sn)[N], double (&cs)[N])
 {
+    // The octant logic is kept in booleans (lane masks in SGPRs, combined by scalar instructions) rather
+    // than in integer counters: m = number of thresholds passed, m & 1 = parity of the four compares,
+    // m >= 3 <=> third compare, m == 2 <=> second and not third, 90 m = a select among exact constants.
     double h[N], l[N], S[N], C[N], r[N], d[N];
-    int ms[N], mc[N];
+    bool sodd[N], s_ge3[N], s_eq2[N], codd[N], c_eq1[N], c_eq2[N];
     TPG_UNROLL for (int e = 0; e < N; ++e) {
         r[e] = absD(x[e]);
-        ms[e] = (int)(r[e] >= 45.0) + (int)(r[e] > 135.0) + (int)(r[e] >= 225.0) + (int)(r[e] > 315.0);
-        mc[e] = (int)(r[e] > 45.0) + (int)(r[e] >= 135.0) + (int)(r[e] > 225.0) + (int)(r[e] >= 315.0);
-        d[e] = (double)(90 * ms[e]) - r[e];
+        const bool s1 = r[e] >= 45.0, s2 = r[e] > 135.0, s3 = r[e] >= 225.0, s4 = r[e] > 315.0;    // sind's octants
+        const bool c1 = r[e] > 45.0, c2 = r[e] >= 135.0, c3 = r[e] > 225.0, c4 = r[e] >= 315.0;    // cosd's octants
+        sodd[e] = (s1 != s2) != (s3 != s4); s_ge3[e] = s3; s_eq2[e] = s2 && !s3;
+        codd[e] = (c1 != c2) != (c3 != c4); c_eq1[e] = c1 && !c2; c_eq2[e] = c2 && !c3;
+        double m90 = 0.0;
+        m90 = s1 ? 90.0 : m90; m90 = s2 ? 180.0 : m90; m90 = s3 ? 270.0 : m90; m90 = s4 ? 360.0 : m90;
+        d[e] = m90 - r[e];
         double t = absD(d[e]);
         double hh = t * kDeg2Rad;
         l[e] = fmaD(t, kDeg2Rad, -hh) + t * kDeg2RadLo;
@@ -274,18 +281,18 @@ template <int N> TPG_DEV void sincosd_b(const double (&x)[N], double (&sn)[N], d
     TPG_UNROLL for (int e = 0; e < N; ++e) {
         const double sg = csign(1.0, x[e]), nsg = -sg;
         const double dsg = csign(1.0, d[e]);
-        const double bs = (ms[e] & 1) ? C[e] : S[e];
+        const double bs = sodd[e] ? C[e] : S[e];
         const double f2 = dsg * sg;
         double fs = sg;
-        fs = ms[e] >= 3 ? nsg : fs;
-        fs = ms[e] == 2 ? f2 : fs;
+        fs = s_ge3[e] ? nsg : fs;
+        fs = s_eq2[e] ? f2 : fs;
         sn[e] = fs * bs;
-        const double bc = (mc[e] & 1) ? S[e] : C[e];
+        const double bc = codd[e] ? S[e] : C[e];
         const double a1 = 90.0 - r[e], a3 = r[e] - 270.0;
-        const double arg = mc[e] == 1 ? a1 : a3;
+        const double arg = c_eq1[e] ? a1 : a3;
         const double fodd = csign(1.0, arg);
-        const double feven = mc[e] == 2 ? -1.0 : 1.0;
-        const double fc = (mc[e] & 1) ? fodd : feven;
+        const double feven = c_eq2[e] ? -1.0 : 1.0;
+        const double fc = codd[e] ? fodd : feven;
         cs[e] = fc * bc;
     }
 }
