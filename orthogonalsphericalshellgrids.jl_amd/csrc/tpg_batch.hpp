@@ -141,15 +141,19 @@ template <int N> TPG_DEV void atan_b(const double (&x)[N], double (&out)[N])
     }
 }
 
-// Range-reduction constants of atan_b, one row per msun interval id = 0..3:
+// Range-reduction constants of atan, one row per msun interval (the "direct" interval |x| < 0.4375 first):
 //   t = (p*ax - q) / (r + s*ax),  result = hi - ((t*poly - lo) - t)
-// (p*ax, s*ax are exact for p,s in {0,1,2}; 1.5*ax rounds exactly as the scalar code's 1.5*ax).
-// Looked up per lane from LDS (3 ds_read_b128) instead of 24 v_cndmask + the unused candidates.
+// (p*ax, s*ax are exact for p,s in {0,1,2}; 1.5*ax rounds exactly as the scalar code's 1.5*ax).  The direct
+// interval is the row p = 1, q = 0, r = 1, s = 0, hi = lo = 0: t = ax / 1 = ax exactly and
+// 0 - ((t*poly - 0) - t) is the scalar branch's t - t*poly bit for bit (both differences are exact
+// negations of each other; a zero difference is +0 either way).
+// Looked up per lane from LDS (3 ds_read_b128) instead of selects over the unused candidates.
 struct AtanRow { double p, q, r, s, hi, lo; };
-#define TPG_ATAN_TABLE_DOUBLES 24
+#define TPG_ATAN_TABLE_DOUBLES 30
 TPG_DEV void atan_table_init(double* tab, int tid)
 {
-    const double rows[4][6] = {
+    const double rows[5][6] = {
+        { 1.0, 0.0, 1.0, 0.0, 0.0, 0.0 },                                        // [0, 0.4375): direct
         { 2.0, 1.0, 2.0, 1.0, 0x1.dac670561bb4fp-2, 0x1.a2b7f222f65e2p-56 },     // [0.4375, 0.6875): (2x-1)/(2+x), atan(0.5)
         { 1.0, 1.0, 1.0, 1.0, 0x1.921fb54442d18p-1, 0x1.1a62633145c07p-55 },     // [0.6875, 1.1875): (x-1)/(x+1),  atan(1)
         { 1.0, 1.5, 1.0, 1.5, 0x1.f730bd281f69bp-1, 0x1.007887af0cbbdp-56 },     // [1.1875, 2.4375): (x-1.5)/(1+1.5x), atan(1.5)
@@ -162,23 +166,22 @@ TPG_DEV void atan_table_init(double* tab, int tid)
 // uses min(ax, 2^1000) so that an infinite argument (y/x at x = +-0) still gives 0*ax - 1 = -1.
 template <int N> TPG_DEV void atan_tab_b(const double (&x)[N], double (&out)[N], const double* tab)
 {
-    double t[N], hi[N], lo[N], s[N], ax[N];
-    bool direct[N];
+    double t[N], hi[N], lo[N], s[N];
     TPG_UNROLL for (int e = 0; e < N; ++e) {
-        ax[e] = absD(x[e]);
-        direct[e] = ax[e] < 0.4375;
-        const int id = (int)(ax[e] >= 0.6875) + (int)(ax[e] >= 1.1875) + (int)(ax[e] >= 2.4375);
-        const AtanRow row = *reinterpret_cast<const AtanRow*>(tab + 6 * id);
+        const double ax = absD(x[e]);
+        int off = 0;                                    // doubles into the table: a select, not a sum and a multiply
+        off = ax >= 0.4375 ? 6 : off; off = ax >= 0.6875 ? 12 : off; off = ax >= 1.1875 ? 18 : off; off = ax >= 2.4375 ? 24 : off;
+        const AtanRow row = *reinterpret_cast<const AtanRow*>(tab + off);
         hi[e] = row.hi; lo[e] = row.lo;
-        const double axn = ax[e] > 0x1p1000 ? 0x1p1000 : ax[e];      // NaN stays NaN
+        const double axn = ax > 0x1p1000 ? 0x1p1000 : ax;      // NaN stays NaN (and selects the direct row)
         const double num = row.p * axn - row.q;
         // den in [1, 1.5 * 2^1000] (axn, not ax: for ax >= 2^1000 the quotient -1/den is below 2^-999 either
         // way, its square underflows to 0 and hi - ((t*0 - lo) - t) rounds to hi - (-lo) regardless), so the
         // unscaled division is exact-equivalent; a NaN argument propagates through both forms
         const double den = row.r + row.s * axn;
         double q = tpgm::div_nr(num, den);
-        asm volatile("" : "+v"(q));
-        t[e] = direct[e] ? ax[e] : q;
+        asm volatile("" : "+v"(q));          // scheduling fence: keeps the live set of 4-wave kernels under 128 VGPRs
+        t[e] = q;
     }
     {
         double z[N], w[N], s1[N], s2[N];
@@ -197,8 +200,7 @@ template <int N> TPG_DEV void atan_tab_b(const double (&x)[N], double (&out)[N],
     }
     TPG_UNROLL for (int e = 0; e < N; ++e) {
         const double ts = t[e] * s[e];
-        const double rd = t[e] - ts, rg = hi[e] - ((ts - lo[e]) - t[e]);
-        const double r = direct[e] ? rd : rg;
+        const double r = hi[e] - ((ts - lo[e]) - t[e]);
         out[e] = csign(r, x[e]);
     }
 }
