@@ -164,7 +164,8 @@ TPG_DEV void atan_table_init(double* tab, int tid)
 // atan(x), all x, with the interval constants taken from the LDS table (see atan_b for the
 // value-equivalence of dropping the msun early-outs).  p = 0 on the last interval: the numerator
 // uses min(ax, 2^1000) so that an infinite argument (y/x at x = +-0) still gives 0*ax - 1 = -1.
-template <int N> TPG_DEV void atan_tab_b(const double (&x)[N], double (&out)[N], const double* tab)
+// FINITE = true: the caller guarantees finite arguments (e.g. sqrt(x^2 + y^2)) and the clamp is skipped.
+template <int N, bool FINITE = false> TPG_DEV void atan_tab_b(const double (&x)[N], double (&out)[N], const double* tab)
 {
     double t[N], hi[N], lo[N], s[N];
     TPG_UNROLL for (int e = 0; e < N; ++e) {
@@ -173,7 +174,7 @@ template <int N> TPG_DEV void atan_tab_b(const double (&x)[N], double (&out)[N],
         off = ax >= 0.4375 ? 6 : off; off = ax >= 0.6875 ? 12 : off; off = ax >= 1.1875 ? 18 : off; off = ax >= 2.4375 ? 24 : off;
         const AtanRow row = *reinterpret_cast<const AtanRow*>(tab + off);
         hi[e] = row.hi; lo[e] = row.lo;
-        const double axn = ax > 0x1p1000 ? 0x1p1000 : ax;      // NaN stays NaN (and selects the direct row)
+        const double axn = (!FINITE && ax > 0x1p1000) ? 0x1p1000 : ax;      // NaN stays NaN (and selects the direct row)
         const double num = row.p * axn - row.q;
         // den in [1, 1.5 * 2^1000] (axn, not ax: for ax >= 2^1000 the quotient -1/den is below 2^-999 either
         // way, its square underflows to 0 and hi - ((t*0 - lo) - t) rounds to hi - (-lo) regardless), so the

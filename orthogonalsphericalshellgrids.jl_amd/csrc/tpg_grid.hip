@@ -482,7 +482,7 @@ __device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc,
 #pragma unroll
     for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt_nr(y[k] * y[k] + x[k] * x[k]); }
     tpgb::atan_tab_b<4>(q, at1, atab);
-    tpgb::atan_tab_b<4>(rr, at2, atab);
+    tpgb::atan_tab_b<4, true>(rr, at2, atab);      // rr = sqrt(...) of finite table products
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         double l = -kC180Pi * at1[k];                          // :77 (no pole below row Ny)
@@ -515,7 +515,7 @@ __device__ __forceinline__ void points_fast2(const GridK& g, const LaneConst& lc
     for (int h = 0; h < 4; h += 2) {
         double qa[2] = { q[h], q[h + 1] }, ra[2] = { rr[h], rr[h + 1] }, o1[2], o2[2];
         tpgb::atan_tab_b<2>(qa, o1, atab);
-        tpgb::atan_tab_b<2>(ra, o2, atab);
+        tpgb::atan_tab_b<2, true>(ra, o2, atab);      // ra = sqrt(...) of finite table products
         at1[h] = o1[0]; at1[h + 1] = o1[1]; at2[h] = o2[0]; at2[h + 1] = o2[1];
     }
 #pragma unroll
@@ -667,8 +667,7 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
             for (int e = 0; e < 4; ++e) {
                 double h = s1[e] * s1[e] + xc_[hb + e] * yc_[hb + e] * (s2[e] * s2[e]);
                 const double r = sqrt_nr(h);              // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles)
-                const double mn = r < 1.0 ? r : 1.0;
-                rm[e] = r != r ? r : mn;
+                rm[e] = !(r >= 1.0) ? r : 1.0;        // min(r, 1) with NaN kept: one compare
             }
             if (tpgb::asin_small_b<4>(rm, as)) {
 #pragma unroll
@@ -860,8 +859,7 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         for (int e = 0; e < 2; ++e) {
             double h = s1[e] * s1[e] + X[e].ca * Y[e].ca * (s2[e] * s2[e]);
             const double r = sqrt_nr(h);              // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles)
-            const double mn = r < 1.0 ? r : 1.0;
-            rm[e] = r != r ? r : mn;
+            rm[e] = !(r >= 1.0) ? r : 1.0;        // min(r, 1) with NaN kept: one compare
         }
         if (tpgb::asin_small_b<2>(rm, as)) {
 #pragma unroll
