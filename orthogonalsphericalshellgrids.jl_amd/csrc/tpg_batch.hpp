@@ -300,6 +300,13 @@ template <int N> TPG_DEV void sincosd_b(const double (&x)[N], double (&sn)[N], d
     }
 }
 
+// fmod(x, 360) for 0 <= x < 720 (the second application in ((l % 360) + 360) % 360: l % 360 is in (-360, 360))
+TPG_DEV double fmod360_pos(double x)
+{
+    const double w = x - 360.0;
+    return x < 360.0 ? x : w;
+}
+
 // exact fmod(x, 360) for |x| < 720 (select form of tpgm::fmod360)
 TPG_DEV double fmod360_small(double x)
 {

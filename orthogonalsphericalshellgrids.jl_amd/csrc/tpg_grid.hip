@@ -480,7 +480,7 @@ __device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc,
     double y[4] = { lc.aclF * shC, lc.aclC * shC, lc.aclF * shF, lc.aclC * shF };          // :68
     double q[4], rr[4], at1[4], at2[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt_nr(y[k] * y[k] + x[k] * x[k]); }
+    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt_nr<true>(y[k] * y[k] + x[k] * x[k]);   /* > 0: no pole below row Ny */ }
     tpgb::atan_tab_b<4>(q, at1, atab);
     tpgb::atan_tab_b<4, true>(rr, at2, atab);      // rr = sqrt(...) of finite table products
 #pragma unroll
@@ -489,7 +489,7 @@ __device__ __forceinline__ void points_fast(const GridK& g, const LaneConst& lc,
         s.phi[k] = 90.0 - kC360Pi * at2[k];                    // :78
         l += lc.hemi;                                          // :82
         l += g.fplp90;                                         // :86
-        s.lam[k] = tpgb::fmod360_small(tpgb::fmod360_small(l) + 360.0);   // :87
+        s.lam[k] = tpgb::fmod360_pos(tpgb::fmod360_small(l) + 360.0);     // :87
         s.a[k] = s.phi[k] * kDeg2Rad;
     }
     if (tpgb::cos_b<4>(s.a, s.ca)) {
@@ -510,7 +510,7 @@ __device__ __forceinline__ void points_fast2(const GridK& g, const LaneConst& lc
     double y[4] = { lc.aclF * shC, lc.aclC * shC, lc.aclF * shF, lc.aclC * shF };          // :68
     double q[4], rr[4], at1[4], at2[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt_nr(y[k] * y[k] + x[k] * x[k]); }
+    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt_nr<true>(y[k] * y[k] + x[k] * x[k]);   /* > 0: no pole below row Ny */ }
 #pragma unroll
     for (int h = 0; h < 4; h += 2) {
         double qa[2] = { q[h], q[h + 1] }, ra[2] = { rr[h], rr[h + 1] }, o1[2], o2[2];
@@ -524,7 +524,7 @@ __device__ __forceinline__ void points_fast2(const GridK& g, const LaneConst& lc
         s.phi[k] = 90.0 - kC360Pi * at2[k];                    // :78
         l += lc.hemi;                                          // :82
         l += g.fplp90;                                         // :86
-        s.lam[k] = tpgb::fmod360_small(tpgb::fmod360_small(l) + 360.0);   // :87
+        s.lam[k] = tpgb::fmod360_pos(tpgb::fmod360_small(l) + 360.0);     // :87
         s.a[k] = s.phi[k] * kDeg2Rad;
     }
     double sn[4], cs[4];

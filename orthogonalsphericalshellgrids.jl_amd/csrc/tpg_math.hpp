@@ -62,7 +62,8 @@ TPG_DEV double div_nr(double a, double b)
     e = fmaD(-b, q, a);
     return fmaD(e, r, q);
 }
-TPG_DEV double sqrt_nr(double x)
+// NONZERO = true: the caller guarantees x > 0 (no select for the zero case)
+template <bool NONZERO = false> TPG_DEV double sqrt_nr(double x)
 {
     const double r = __builtin_amdgcn_rsq(x);
     double g = x * r;
@@ -74,7 +75,7 @@ TPG_DEV double sqrt_nr(double x)
     g = fmaD(d, h, g);
     d = fmaD(-g, g, x);
     g = fmaD(d, h, g);
-    return x == 0.0 ? x : g;
+    return (!NONZERO && x == 0.0) ? x : g;
 }
 TPG_DEV double csign(double mag, double sgn) { return __builtin_copysign(mag, sgn); }
 
