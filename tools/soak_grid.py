@@ -1,0 +1,27 @@
+"""GPU box: extended randomised soak of tpg_build_grid against the oracle (bit-exact, whole padded arrays):
+sizes up to 400 x 120, continuous random poles / south / first-pole longitude / radius, both element types,
+both the tile and the marching kernels.  usage: python tools/soak_grid.py [trials] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import orthogonalsphericalshellgrids.jl_amd as osg
+from oracle import oracle
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for t in range(trials):
+    Nx = 2 * int(rng.integers(1, 200)); Ny = int(rng.integers(2, 121))
+    Hx = int(rng.integers(1, min(Nx, 6) + 1)); Hy = int(rng.integers(1, min(Ny, 6) + 1))
+    kw = dict(size=(Nx, Ny, 1), halo=(Hx, Hy, 1), north_poles_latitude=float(np.round(rng.uniform(20, 88), int(rng.integers(0, 6)))),
+              first_pole_longitude=float(np.round(rng.uniform(-200, 380), int(rng.integers(0, 6)))),
+              southernmost_latitude=float(np.round(rng.uniform(-88, 15), int(rng.integers(0, 6)))), radius=float(rng.choice([1.0, 6371e3, 3389.5e3])))
+    dtype, tdt = ((np.float64, torch.float64), (np.float32, torch.float32))[t % 5 == 0]
+    os.environ["TPG_CELLS_VARIANT"] = "3" if t % 3 else "2"
+    ref = oracle.build_grid(dtype=dtype, **kw)
+    g = osg.TripolarGrid(osg.GPU(0), tdt, **kw)
+    for name, r in ref.items():
+        if not np.array_equal(getattr(g, name).cpu().numpy(), r, equal_nan=True):
+            bad += 1; print("MISMATCH", t, kw, name); break
+    if t % 50 == 49: print(f"{t + 1} trials, {bad} mismatches", flush=True)
+print("done:", trials, "trials,", bad, "mismatches")
+sys.exit(1 if bad else 0)
