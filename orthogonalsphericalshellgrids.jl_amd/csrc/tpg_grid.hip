@@ -720,12 +720,47 @@ __global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, March
 // register state: a block of 64 x R threads evaluates one point set per thread (step s = FC(s), CC(s),
 // FF(s+1), CF(s+1), exactly as one marching step), parks {lambda, a, cos a[, X, Y, Z]} in LDS
 // (18 doubles x 64 x R), and after ONE barrier every thread with a south and east/west neighbour
-// inside the tile computes its cell from its own registers plus 51 LDS reads.  Row p = 0 and lanes
-// 0 / 63 are aprons (tiles overlap by one point row / two columns): (R-1)/R x 62/64 of the lanes emit.
+// inside the tile computes its cell from its own registers plus 48 LDS reads.  Row p = 0 and lanes
+// 0 / 63 are aprons (tiles overlap by one point row / two columns): (R-1)/R x 62/64 of the lanes emit;
+// the apron wave, which has no cell row, spends phase 2 on one of the eight haversines (Dy_ff) of all rows.
 // A wave owns one point row, so the special rows (0, Ny) are a wave-uniform branch to coord().
 // Same arithmetic as the other K1 forms: bit-identical results.
 template <int R> struct TileLds { double v[18][R][64]; };
 enum { L_FC = 0, L_CC = 3, L_FF = 9, L_CF = 15 };    // field bases: FC(lam,a,ca) CC(lam,a,ca,X,Y,Z) FF(6) CF(3)
+
+// N haversines at once: x = first argument, y = second, each {lambda, deg2rad(phi), cos}; the same
+// operation sequence as hav() with the batch forms (rare arguments fall back to the scalar functions)
+template <int N>
+__device__ __forceinline__ void hav_batch(const Nb (&X)[N], const Nb (&Y)[N], double Rad, double (&d)[N])
+{
+    double hp[N], hl[N], s1[N], s2[N], rm[N], as[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        double dl = (Y[e].lam - X[e].lam) * kDeg2Rad;
+        double dp = Y[e].a - X[e].a;
+        hp[e] = dp / 2; hl[e] = dl / 2;
+    }
+    if (tpgb::sin_small_b<N>(hp, s1)) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) s1[e] = sinD(hp[e]);
+    }
+    if (tpgb::sin_small_b<N>(hl, s2)) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) s2[e] = sinD(hl[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        double h = s1[e] * s1[e] + X[e].ca * Y[e].ca * (s2[e] * s2[e]);
+        const double r = sqrt_nr(h);              // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles)
+        rm[e] = !(r >= 1.0) ? r : 1.0;        // min(r, 1) with NaN kept: one compare
+    }
+    if (tpgb::asin_small_b<N>(rm, as)) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) as[e] = asinD(rm[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) d[e] = 2 * (Rad * as[e]);
+}
 
 template <typename T, bool NT, int R>
 __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, int tiles_x)
@@ -790,7 +825,29 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         L[L_CF + 0][p][lane] = q.lam[3]; L[L_CF + 1][p][lane] = q.a[3]; L[L_CF + 2][p][lane] = q.ca[3];
     }
     __syncthreads();                                                         // the only barrier: point sets in LDS
-    if (!active_row || p == 0 || s < g.jm_lo || !col_emit) return;          // aprons and idle rows are done
+    if (p == 0) {
+        // The apron wave has no cell row of its own: instead of idling through phase 2 it computes one of the
+        // eight haversines, Dy_ff = hav(FC(i,s), FC(i,s-1)), for every row of the tile from LDS (two rows at a time)
+        if (!col_emit) return;
+        double (*L)[R][64] = lds.v;
+#pragma unroll 1
+        for (int r = 1; r < R; r += 2) {
+            const int sa = s0 + r, sb = sa + 1;
+            if (sa > g.jm_hi) break;
+            const bool two = (r + 1 < R) && sb <= g.jm_hi;
+            const int rb = two ? r + 1 : r;
+            Nb X[2] = { Nb{ L[L_FC + 0][r][lane], L[L_FC + 1][r][lane], L[L_FC + 2][r][lane] },
+                        Nb{ L[L_FC + 0][rb][lane], L[L_FC + 1][rb][lane], L[L_FC + 2][rb][lane] } };
+            Nb Y[2] = { Nb{ L[L_FC + 0][r - 1][lane], L[L_FC + 1][r - 1][lane], L[L_FC + 2][r - 1][lane] },
+                        Nb{ L[L_FC + 0][rb - 1][lane], L[L_FC + 1][rb - 1][lane], L[L_FC + 2][rb - 1][lane] } };
+            double dd2[2];
+            hav_batch<2>(X, Y, Rad, dd2);
+            if (sa >= g.jm_lo) put<T, NT>(o, TPG_DY_FF, rowoff(sa), dd2[0]);
+            if (two && sb >= g.jm_lo) put<T, NT>(o, TPG_DY_FF, rowoff(sb), dd2[1]);
+        }
+        return;
+    }
+    if (!active_row || s < g.jm_lo || !col_emit) return;                    // idle rows and apron lanes are done
 
     // ---- phase 2: the cell (i, s) from own registers + LDS neighbours, loaded just in time so that the
     //      live set stays under 128 VGPRs (4 waves/SIMD supply the ILP; batches of 2 suffice)
@@ -834,44 +891,25 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
                         Nb{ q.lam[2], q.a[2], q.ca[2] }, Nb{ q.lam[3], q.a[3], q.ca[3] } };   // fc cc ff cf
     double d[8];
 #pragma unroll
-    for (int hb = 0; hb < 8; hb += 2) {
+    for (int hb = 0; hb < 6; hb += 2) {
         Nb X[2], Y[2];
         if (hb == 0)      { X[0] = ld(L_FC, p, le); Y[0] = own[0];            X[1] = own[1];            Y[1] = ld(L_CC, p, lw); }
         else if (hb == 2) { X[0] = ld(L_FF, pm, le); Y[0] = ld(L_FF, pm, lane); X[1] = ld(L_CF, pm, lane); Y[1] = ld(L_CF, pm, lw); }
-        else if (hb == 4) { X[0] = own[3];           Y[0] = ld(L_CF, pm, lane); X[1] = own[2];            Y[1] = ld(L_FF, pm, lane); }
-        else              { X[0] = own[1];           Y[0] = ld(L_CC, pm, lane); X[1] = own[0];            Y[1] = ld(L_FC, pm, lane); }
-        double hp[2], hl[2], s1[2], s2[2], rm[2], as[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            double dl = (Y[e].lam - X[e].lam) * kDeg2Rad;
-            double dp = Y[e].a - X[e].a;
-            hp[e] = dp / 2; hl[e] = dl / 2;
-        }
-        if (tpgb::sin_small_b<2>(hp, s1)) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) s1[e] = sinD(hp[e]);
-        }
-        if (tpgb::sin_small_b<2>(hl, s2)) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) s2[e] = sinD(hl[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            double h = s1[e] * s1[e] + X[e].ca * Y[e].ca * (s2[e] * s2[e]);
-            const double r = sqrt_nr(h);              // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles)
-            rm[e] = !(r >= 1.0) ? r : 1.0;        // min(r, 1) with NaN kept: one compare
-        }
-        if (tpgb::asin_small_b<2>(rm, as)) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) as[e] = asinD(rm[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) d[hb + e] = 2 * (Rad * as[e]);
+        else              { X[0] = own[3];           Y[0] = ld(L_CF, pm, lane); X[1] = own[2];            Y[1] = ld(L_FF, pm, lane); }
+        double dd2[2];
+        hav_batch<2>(X, Y, Rad, dd2);
+        d[hb] = dd2[0]; d[hb + 1] = dd2[1];
+    }
+    {   // Dy_cf here; Dy_ff is the apron wave's
+        Nb X[1] = { own[1] }, Y[1] = { ld(L_CC, pm, lane) };
+        double dd1[1];
+        hav_batch<1>(X, Y, Rad, dd1);
+        d[6] = dd1[0];
     }
     put<T, NT>(o, TPG_DX_CC, off, d[0]); put<T, NT>(o, TPG_DX_FC, off, d[1]);
     put<T, NT>(o, TPG_DX_CF, off, d[2]); put<T, NT>(o, TPG_DX_FF, off, d[3]);
     put<T, NT>(o, TPG_DY_CC, off, d[4]); put<T, NT>(o, TPG_DY_FC, off, d[5]);
-    put<T, NT>(o, TPG_DY_CF, off, d[6]); put<T, NT>(o, TPG_DY_FF, off, d[7]);
+    put<T, NT>(o, TPG_DY_CF, off, d[6]);
     put<T, NT>(o, TPG_AZ_FC, off, d[5] * d[1]);
     put<T, NT>(o, TPG_AZ_CF, off, d[6] * d[2]);
 }
