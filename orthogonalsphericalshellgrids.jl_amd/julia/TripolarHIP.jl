@@ -146,6 +146,31 @@ function zipper_fill!(fields::Vector, bcs::Vector, locs::Vector, grid)
 end
 
 """
+    fill_zipper_and_periodic!(fields::Vector, bcs::Vector{<:ZBC}, locs, grid)
+
+The whole `fill_halo_regions!` of fields on a serial tripolar grid (zipper, then periodic west / east:
+order pinned by test/test_zipper_boundary_conditions.jl:42-45) in one call; small (2-D) fields such as
+the split-explicit free surface take a single fused launch inside the library.
+"""
+function fill_zipper_and_periodic!(fields::Vector, bcs::Vector, locs::Vector, grid)
+    Nx, Ny, Nz = size(grid)
+    Hx, Hy, Hz = Oceananigans.Grids.halo_size(grid)
+    FT = eltype(parent(first(fields)))
+    ptrs = Ptr{Cvoid}[device_pointer(f) for f in fields]
+    xloc = Int8[loc_code(l[1]) for l in locs]
+    yloc = Int8[loc_code(l[2]) for l in locs]
+    sign = Int32[bc.condition for bc in bcs]
+    GC.@preserve fields begin
+        check(ccall((:tpg_fill_halo_regions, libtripolar), Cint,
+                    (Ptr{Ptr{Cvoid}}, Cint, Ptr{Int8}, Ptr{Int8}, Ptr{Int32},
+                     Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
+                    ptrs, length(fields), xloc, yloc, sign, Nx, Ny, Nz, Hx, Hy, Hz, 1,
+                    ft_code(FT), current_stream()))
+    end
+    return nothing
+end
+
+"""
     pack_y_halo!(buffer, fields, side, grid) / unpack_y_halo!(fields, buffer, side, grid)
 
 Device-side gather / scatter of the Hy seam rows of a y-slab partition; the transport (MPI.jl
@@ -157,12 +182,16 @@ function pack_y_halo!(buffer, fields::Vector, side::Integer, grid; pack::Bool = 
     Hx, Hy, Hz = Oceananigans.Grids.halo_size(grid)
     FT = eltype(parent(first(fields)))
     ptrs = Ptr{Cvoid}[device_pointer(f) for f in fields]
-    fn = pack ? :tpg_pack_y_halo : :tpg_unpack_y_halo
     GC.@preserve fields buffer begin
-        check(ccall((fn, libtripolar), Cint,
-                    (Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
-                    ptrs, length(fields), device_pointer(buffer), side, Nx, Ny, Nz, Hx, Hy, Hz,
-                    ft_code(FT), current_stream()))
+        # (the symbol of a ccall must be a literal: two call sites, one per direction)
+        status = pack ?
+            ccall((:tpg_pack_y_halo, libtripolar), Cint,
+                  (Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
+                  ptrs, length(fields), device_pointer(buffer), side, Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), current_stream()) :
+            ccall((:tpg_unpack_y_halo, libtripolar), Cint,
+                  (Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
+                  ptrs, length(fields), device_pointer(buffer), side, Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), current_stream())
+        check(status)
     end
     return nothing
 end
