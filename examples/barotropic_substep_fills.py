@@ -50,12 +50,7 @@ def main():
     e1.record(); torch.cuda.synchronize()
     planned = e0.elapsed_time(e1) / reps
 
-    graph = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side), torch.cuda.graph(graph, stream=side):
-        cycle()
-    torch.cuda.current_stream().wait_stream(side)
+    graph = plan.graph(repeat=SUBSTEPS)              # the whole sub-cycle as one HIP graph
     graph.replay(); torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):

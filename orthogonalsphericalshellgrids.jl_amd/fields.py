@@ -224,6 +224,25 @@ class HaloFillPlan:
         return None
 
 
+    def graph(self, repeat=1):
+        """Capture `repeat` consecutive runs of this plan into one HIP graph (torch.cuda.CUDAGraph) and return
+        it; `graph.replay()` then issues the whole sequence with a single launch -- the fills of a
+        split-explicit sub-cycle are launch-bound, 2.7 us instead of 7 us per fill.
+        Serial grids only: a seam exchange (torch.distributed) cannot be captured."""
+        if any(seam is not None for _, _, seam, _ in self._steps):
+            raise ValueError("HaloFillPlan.graph: plans with a distributed seam exchange cannot be captured")
+        self()                                           # first-call work (occupancy queries, lazy module load) outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.cuda.graph(g, stream=side):
+            for _ in range(repeat):
+                self()
+        torch.cuda.current_stream().wait_stream(side)
+        return g
+
+
 def halo_fill_plan(fields, *, exchange=None):
     return HaloFillPlan(fields, exchange=exchange)
 

@@ -286,3 +286,25 @@ def test_halo_fill_plan_equals_fill_halo_regions(osg, oracle, gpu):
         for f, h, (xl, yl, sg) in zip((u, c, eta), hosts, ((1, 0, -1), (0, 0, 1), (0, 0, 1))):
             oracle.fill_halo_regions(h, xl, yl, sg, (size[0], size[1], f.Nz), (halo[0], halo[1], f.Hz))
             assert np.array_equal(f.data.cpu().numpy(), h), f.loc
+
+
+def test_halo_fill_plan_graph_replay(osg, oracle, gpu):
+    """HaloFillPlan.graph(repeat): `repeat` fills captured into one HIP graph; a replay applies them all
+    (two fills of a -1 x-Face field flip the self-mapped cell of row Ny twice)"""
+    size, halo = (64, 32, 1), (4, 4, 1)
+    grid = osg.TripolarGrid(size=size, halo=halo)
+    rng = np.random.default_rng(31)
+    U = osg.Field((osg.Face, osg.Center, None), grid)
+    eta = osg.Field((osg.Center, osg.Center, None), grid)
+    hosts = []
+    for f in (U, eta):
+        h = rng.uniform(-1, 1, tuple(f.data.shape)); hosts.append(h)
+    g = osg.halo_fill_plan((U, eta)).graph(repeat=2)
+    for f, h in zip((U, eta), hosts):                       # (re)load the inputs after the capture's warm-up runs
+        f.data.copy_(torch.from_numpy(h))
+    g.replay()
+    torch.cuda.synchronize()
+    for f, h, (xl, yl, sg) in zip((U, eta), hosts, ((1, 0, -1), (0, 0, 1))):
+        for _ in range(2):
+            oracle.fill_halo_regions(h, xl, yl, sg, (size[0], size[1], 1), (halo[0], halo[1], 0))
+        assert np.array_equal(f.data.cpu().numpy(), h), f.loc
