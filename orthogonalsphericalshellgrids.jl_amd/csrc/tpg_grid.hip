@@ -928,9 +928,9 @@ __device__ __forceinline__ void array_loc(int q, int& xl, int& yl)
 
 struct HaloRegions {
     int nA;   // x-halo columns of evaluated rows: (jm_hi-jm_lo+1) * 2Hx
-    int nB;   // north rows j = Ny+1..Ny+Hy (north rank): Hy * sx
+    int nB;   // north rows j = Ny+1..jend+Hy present in the band (all Hy of them on the north rank)
     int nC;   // south rows j < 1 present in the band (+ row 1 when K3 is merged): (nsouth + row1) * sx
-    int nD;   // row-Ny substitution cells i = Nx/2+1..Nx (north rank): Nx/2
+    int nD;   // row-Ny substitution cells i = Nx/2+1..Nx (bands that contain row Ny): Nx/2
     int nsouth;
     int merged_south;   // 1: this launch also writes the lat-lon continuation rows j <= 1 of the 12 metrics (K3)
 };
@@ -1151,10 +1151,12 @@ int tpg_build_grid(const tpg_params* p, void* const out[TPG_NUM_ARRAYS], void* w
 
     HaloRegions h;
     h.nA = (g.jm_hi - g.jm_lo + 1) * 2 * g.Hx;
-    h.nB = (p->jend == p->Ny) ? g.Hy * g.sx : 0;
+    // north fold rows / row-Ny substitution: on the north rank, and on any band whose halo reaches them
+    // (bands thinner than the halo: the reference slices them out of the global padded arrays)
+    h.nB = (p->jend + p->Hy > p->Ny) ? (p->jend + p->Hy - p->Ny) * g.sx : 0;
     h.nsouth = (1 - (p->jstart - p->Hy)) > 0 ? (1 - (p->jstart - p->Hy)) : 0;   // rows j < 1 in the band
     h.nC = h.nsouth * g.sx;
-    h.nD = (p->jend == p->Ny) ? p->Nx / 2 : 0;
+    h.nD = (p->jend + p->Hy >= p->Ny) ? p->Nx / 2 : 0;
 
     if (p->ft == TPG_F64) return launch_build<double>(g, o, h, s);
     return launch_build<float>(g, o, h, s);

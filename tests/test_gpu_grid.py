@@ -142,6 +142,21 @@ def test_latitude_bands_equal_slices_of_the_global_grid(osg, oracle, gpu, R):
             assert np.array_equal(got, ref[jstart - 1:jend + 2 * halo[1]], equal_nan=True), (r, name)
 
 
+@pytest.mark.parametrize("size,halo,R", [((106, 12, 1), (4, 6, 1), 9), ((276, 4, 1), (3, 2, 1), 4), ((150, 8, 1), (4, 6, 1), 2)],
+                         ids=["12rows-9ranks-Hy6", "4rows-4ranks-Hy2", "8rows-2ranks-Hy6"])
+def test_bands_thinner_than_the_halo(osg, oracle, gpu, size, halo, R):
+    """A band whose halo reaches past its neighbour sees row Ny (with its substitution) and north fold rows even
+    though it is not the north rank: the reference slices these out of the global padded arrays
+    (distributed_tripolar_grid.jl:47-49,112-120); found by tools/soak_grid.py."""
+    glob = oracle.build_grid(size, halo=halo)
+    for r in range(R):
+        arch = osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=r)
+        g = osg.TripolarGrid(arch, size=size, halo=halo)
+        jstart, jend = g.jrange
+        for name, ref in glob.items():
+            assert np.array_equal(getattr(g, name).cpu().numpy(), ref[jstart - 1:jend + 2 * halo[1]], equal_nan=True), (r, name)
+
+
 def test_with_halo_and_reconstruct(osg, oracle, gpu):
     g = osg.TripolarGrid(size=(60, 30, 1))
     g2 = osg.with_halo((2, 3, 1), g)                                                   # with_halo.jl:5-23

@@ -22,6 +22,13 @@ for t in range(trials):
     for name, r in ref.items():
         if not np.array_equal(getattr(g, name).cpu().numpy(), r, equal_nan=True):
             bad += 1; print("MISMATCH", t, kw, name); break
+    if t % 4 == 1 and Ny >= 4:                      # a random latitude band of the same grid
+        R = int(rng.integers(2, min(Ny, 9) + 1)); rk = int(rng.integers(0, R))
+        band = osg.TripolarGrid(osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=rk), tdt, **kw)
+        j0, j1 = band.jrange
+        for name, r in ref.items():
+            if not np.array_equal(getattr(band, name).cpu().numpy(), r[j0 - 1:j1 + 2 * Hy], equal_nan=True):
+                bad += 1; print("BAND MISMATCH", t, kw, rk, R, name); break
     if t % 50 == 49: print(f"{t + 1} trials, {bad} mismatches", flush=True)
 print("done:", trials, "trials,", bad, "mismatches")
 sys.exit(1 if bad else 0)
