@@ -28,7 +28,7 @@
  *                        0 thread per cell
  *    TPG_BUILD_NT        1 streaming stores in tpg_build_grid (default), 0 plain stores
  *    TPG_CELLS_STRIP, TPG_CELLS_CAPACITY   strip sizing of the marching variants
- *    TPG_ZIPPER_VARIANT  0..7: row / column work items, streaming loads / stores (default 3)
+ *    TPG_ZIPPER_VARIANT  0..4: row / column work items, streaming loads / stores (default 3)
  *    TPG_FILL_FUSED      0 never / 1 always (where valid) use the fused small-field fill
  */
 #ifndef TRIPOLAR_HIP_H

@@ -128,15 +128,6 @@ __global__ __launch_bounds__(256) void k_zipper_vec(FieldTable ft, ZipArgs a)
 // the first store, so a wave keeps (Hy+2) KiB in flight instead of 1 KiB -- the fold moves only
 // ~70 MB per launch, which makes it latency- rather than bandwidth-limited unless every wave
 // carries many outstanding requests.
-template <typename V> __device__ __forceinline__ void store_sc1(V* p, V v)
-{
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-}
-template <typename V> __device__ __forceinline__ void store_sc0sc1(V* p, V v)
-{
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-}
-
 template <typename T, int W, int HY, bool NTL, int NTS>
 __global__ __launch_bounds__(256) void k_zipper_cols(FieldTable ft, ZipArgs a)
 {
@@ -186,7 +177,7 @@ __global__ __launch_bounds__(256) void k_zipper_cols(FieldTable ft, ZipArgs a)
         for (int e = 0; e < W; ++e) o[e] = s * v[jr - 1][W - 1 - e];
         if (wrap) o[0] = as * w0[jr - 1];
         vec_t* q = reinterpret_cast<vec_t*>(lvl + sx * (prow_ny + jr) + (i - 1));
-        if (NTS == 1) __builtin_nontemporal_store(o, q); else if (NTS == 2) store_sc1(q, o); else if (NTS == 3) store_sc0sc1(q, o); else *q = o;
+        if (NTS == 1) __builtin_nontemporal_store(o, q); else *q = o;
     }
     if (fix) {
         // c[i,Ny] = ifelse(i > Nx/2, sign*c[i',Ny], c[i,Ny]) (:102,:135); i = 1 is never > Nx/2
@@ -402,16 +393,17 @@ void launch_cols(int Hy, dim3 grid, hipStream_t s, const FieldTable& ft, const Z
 }
 
 // TPG_ZIPPER_VARIANT (tools/zipper_tune.sh): 0 row items, 1 columns, 2 columns + nontemporal loads and
-// stores, 3 columns + nontemporal loads (DEFAULT), 4 columns + nontemporal stores, 5 columns + sc1
-// (write-through) stores, 6 nontemporal loads + sc1 stores, 7 nontemporal loads + sc0 sc1 stores.
+// stores, 3 columns + nontemporal loads (DEFAULT), 4 columns + nontemporal stores.
 // Measured at config 3 (kernel events, us): warm / cold-clean / cold-dirty caches
-//   1: 12.6 / 16.8 / 23.6    3: 14.9 / 16.6 / 17.7    5: 11.8 / 16.0 / 25.0    6: 14.7 / 15.8 / 19.1
-// and inside bench.py (rocprofv3 avg, after the grid build): 1: 17.6  3: 16.1  5: 17.4  6: 16.0.
+//   1: 12.6 / 16.8 / 23.6    3: 14.9 / 16.6 / 17.7
+// and inside bench.py (rocprofv3 avg, after the grid build): 1: 17.6  3: 16.1.
 // The fold's sources are not reused soon, so streaming loads cost nothing in a real step and make the
-// kernel robust against a predecessor that left the caches dirty.  Write-through stores remove the
-// end-of-kernel L2 write-back (78 % of 8 TB/s when the lines are cache resident) but do not help the
-// cold case, which is bounded by first-byte latency.  512/1024-thread blocks, two levels per thread
-// and occupancy throttling were measured too and are 3-15 % slower.
+// kernel robust against a predecessor that left the caches dirty.  Write-through (sc1 / sc0 sc1) stores
+// were tried through inline asm: they remove the end-of-kernel L2 write-back when the lines are cache
+// resident (78 % of 8 TB/s) but do not help the cold case, which is bounded by first-byte latency -- and
+// an inline-asm 128-bit store escapes the compiler's hazard recogniser (the next VALU write of its data
+// registers corrupted Float32 folds; found by tools/soak_fill.py), so those forms were removed.
+// 512/1024-thread blocks, two levels per thread and occupancy throttling were measured too: 3-15 % slower.
 int zipper_variant()
 {
     const char* e = getenv("TPG_ZIPPER_VARIANT");
@@ -425,7 +417,7 @@ int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t 
     bool vec = (g.Hx % W == 0) && (g.Nx % W == 0);
     for (int f = 0; f < n && vec; ++f) vec = ((uintptr_t)fields[f] % 16) == 0;
     const int variant = zipper_variant();
-    const bool cols = vec && g.Hy <= 8 && variant != 0;
+    const bool cols = vec && g.Hy >= 1 && g.Hy <= 8 && variant != 0;    // Hy = 0: only the row-Ny substitution remains (row kernels)
 
     FieldTable ft;
     ZipArgs a;
@@ -451,9 +443,6 @@ int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t 
         if (variant == 2)      launch_cols<T, W, true, 1>(g.Hy, grid2, s, ft, a);
         else if (variant == 3) launch_cols<T, W, true, 0>(g.Hy, grid2, s, ft, a);
         else if (variant == 4) launch_cols<T, W, false, 1>(g.Hy, grid2, s, ft, a);
-        else if (variant == 5) launch_cols<T, W, false, 2>(g.Hy, grid2, s, ft, a);
-        else if (variant == 6) launch_cols<T, W, true, 2>(g.Hy, grid2, s, ft, a);
-        else if (variant == 7) launch_cols<T, W, true, 3>(g.Hy, grid2, s, ft, a);
         else                   launch_cols<T, W, false, 0>(g.Hy, grid2, s, ft, a);
     }
     else if (vec) TPG_LAUNCH((k_zipper_vec<T, W>), grid, dim3(256), s, ft, a);
@@ -483,7 +472,9 @@ int tpg_zipper_fill(void* const fields[], int nfields, const int8_t xloc[], cons
         tpg::set_error("level range %d:%d outside %d:%d", kstart, kstart + kcount - 1, 1 - Hz, Nz + Hz);
         return TPG_ERR_INVALID_ARGUMENT;
     }
-    if (kcount == 0 || Hy == 0) return TPG_OK;
+    // Hy = 0 leaves no halo rows to fold, but the row-Ny substitution of the y-Center folds is outside the
+    // j loop of the reference (zipper_boundary_condition.jl:102,135) and still applies
+    if (kcount == 0) return TPG_OK;
     Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
     hipStream_t s = tpg::as_stream(stream);
     for (int f0 = 0; f0 < nfields; f0 += TPG_MAX_FIELDS) {

@@ -39,14 +39,15 @@ def test_build_kernel_variants_agree(osg, gpu, knob, kw):
             assert np.array_equal(a, ref[n], equal_nan=True), (key, n)
 
 
-def test_zipper_kernel_variants_agree(osg, gpu, knob):
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_zipper_kernel_variants_agree(osg, gpu, knob, dtype):
     size, halo = (256, 40, 4), (4, 4, 2)
-    grid = osg.TripolarGrid(size=size, halo=halo)
+    grid = osg.TripolarGrid(osg.GPU(0), dtype, size=size, halo=halo)
     rng = np.random.default_rng(4)
     specs = [(xl, yl, sg) for xl in (0, 1) for yl in (0, 1) for sg in (1, -1)]
-    hosts = [rng.uniform(-1, 1, (4 + 4, 40 + 8, 256 + 8)) for _ in specs]
+    hosts = [rng.uniform(-1, 1, (4 + 4, 40 + 8, 256 + 8)).astype(np.float64 if dtype == torch.float64 else np.float32) for _ in specs]
     outs = {}
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7):
+    for variant in (0, 1, 2, 3, 4):
         knob["TPG_ZIPPER_VARIANT"] = str(variant)
         fs = []
         for (xl, yl, sg), h in zip(specs, hosts):

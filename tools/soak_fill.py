@@ -1,0 +1,38 @@
+"""GPU box: randomised soak of the halo fill (tpg_fill_halo_regions: zipper -> periodic x) against the oracle,
+bit-exact on whole padded arrays: random geometry, locations, signs, element types, zipper variants, fused and
+two-launch forms.  usage: python tools/soak_fill.py [trials] [seed]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import orthogonalsphericalshellgrids.jl_amd as osg
+from orthogonalsphericalshellgrids.jl_amd import _lib
+from oracle import oracle
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+lib = _lib.lib()
+bad = 0
+for t in range(trials):
+    Nx = 2 * int(rng.integers(1, 150)); Ny = int(rng.integers(1, 40)); Nz = int(rng.integers(1, 5))
+    Hx = int(rng.integers(0, min(Nx, 7) + 1)); Hy = int(rng.integers(0, min(Ny, 10) + 1)); Hz = int(rng.integers(0, 3))
+    nf = int(rng.integers(1, 6))
+    dt, tdt, ft = ((np.float64, torch.float64, 1), (np.float32, torch.float32, 0))[t % 3 == 0]
+    os.environ["TPG_ZIPPER_VARIANT"] = str(int(rng.integers(0, 5)))
+    mode = t % 3
+    if mode == 0: os.environ.pop("TPG_FILL_FUSED", None)
+    else: os.environ["TPG_FILL_FUSED"] = str(mode - 1)
+    specs = [(int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([1, -1, 3]))) for _ in range(nf)]
+    hosts = [rng.uniform(-1, 1, (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)).astype(dt) for _ in specs]
+    devs = [torch.from_numpy(h).to(dev) for h in hosts]
+    xl = (C.c_int8 * nf)(*[s[0] for s in specs]); yl = (C.c_int8 * nf)(*[s[1] for s in specs]); sg = (C.c_int32 * nf)(*[s[2] for s in specs])
+    rc = lib.tpg_fill_halo_regions(_lib.ptr_table(devs), nf, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, 1, ft, None)
+    torch.cuda.synchronize()
+    if rc != 0:
+        bad += 1; print("ERROR", t, rc, lib.tpg_last_error(), (Nx, Ny, Nz, Hx, Hy, Hz)); continue
+    for d, h, (x, y, s) in zip(devs, hosts, specs):
+        oracle.fill_halo_regions(h, x, y, s, (Nx, Ny, Nz), (Hx, Hy, Hz))
+        if not np.array_equal(d.cpu().numpy(), h):
+            bad += 1; print("MISMATCH", t, (Nx, Ny, Nz, Hx, Hy, Hz), (x, y, s), dt.__name__, os.environ.get("TPG_FILL_FUSED"), os.environ["TPG_ZIPPER_VARIANT"]); break
+    if t % 500 == 499: print(f"{t + 1} trials, {bad} bad", flush=True)
+print("done:", trials, "trials,", bad, "bad")
+sys.exit(1 if bad else 0)
