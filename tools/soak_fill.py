@@ -22,15 +22,28 @@ for t in range(trials):
     if mode == 0: os.environ.pop("TPG_FILL_FUSED", None)
     else: os.environ["TPG_FILL_FUSED"] = str(mode - 1)
     specs = [(int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([1, -1, 3]))) for _ in range(nf)]
-    hosts = [rng.uniform(-1, 1, (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)).astype(dt) for _ in specs]
-    devs = [torch.from_numpy(h).to(dev) for h in hosts]
+    if t % 11 == 5: nf = int(rng.integers(17, 40)); specs = [(int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([1, -1]))) for _ in range(nf)]   # > TPG_MAX_FIELDS
+    shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
+    hosts = [rng.uniform(-1, 1, shape).astype(dt) for _ in specs]
+    if t % 7 == 3:        # base pointers that are only element-aligned: views one element into a larger buffer
+        n = int(np.prod(shape)); devs = []
+        for h in hosts:
+            buf = torch.empty(n + 1, dtype=tdt, device=dev); v = buf[1:].view(shape); v.copy_(torch.from_numpy(h)); devs.append(v)
+    else:
+        devs = [torch.from_numpy(h).to(dev) for h in hosts]
     xl = (C.c_int8 * nf)(*[s[0] for s in specs]); yl = (C.c_int8 * nf)(*[s[1] for s in specs]); sg = (C.c_int32 * nf)(*[s[2] for s in specs])
-    rc = lib.tpg_fill_halo_regions(_lib.ptr_table(devs), nf, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, 1, ft, None)
+    zip_only = t % 5 == 4
+    if zip_only:          # the fold alone, on a random range of levels (halo levels included)
+        kstart = int(rng.integers(1 - Hz, Nz + 1)); kcount = int(rng.integers(0, Nz + Hz - kstart + 2))
+        rc = lib.tpg_zipper_fill(_lib.ptr_table(devs), nf, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, kstart, kcount, ft, None)
+    else:
+        rc = lib.tpg_fill_halo_regions(_lib.ptr_table(devs), nf, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, 1, ft, None)
     torch.cuda.synchronize()
     if rc != 0:
         bad += 1; print("ERROR", t, rc, lib.tpg_last_error(), (Nx, Ny, Nz, Hx, Hy, Hz)); continue
     for d, h, (x, y, s) in zip(devs, hosts, specs):
-        oracle.fill_halo_regions(h, x, y, s, (Nx, Ny, Nz), (Hx, Hy, Hz))
+        if zip_only: oracle.zipper_fill(h, x, y, s, (Nx, Ny, Nz), (Hx, Hy, Hz), kstart, kcount)
+        else: oracle.fill_halo_regions(h, x, y, s, (Nx, Ny, Nz), (Hx, Hy, Hz))
         if not np.array_equal(d.cpu().numpy(), h):
             bad += 1; print("MISMATCH", t, (Nx, Ny, Nz, Hx, Hy, Hz), (x, y, s), dt.__name__, os.environ.get("TPG_FILL_FUSED"), os.environ["TPG_ZIPPER_VARIANT"]); break
     if t % 500 == 499: print(f"{t + 1} trials, {bad} bad", flush=True)
