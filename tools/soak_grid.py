@@ -1,6 +1,6 @@
 """GPU box: extended randomised soak of tpg_build_grid against the oracle (bit-exact, whole padded arrays):
 sizes up to 400 x 120, continuous random poles / south / first-pole longitude / radius, both element types,
-both the tile and the marching kernels.  usage: python tools/soak_grid.py [trials] [seed]"""
+both the tile and the marching kernels.  usage: python tools/soak_grid.py [trials] [seed] [big]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,7 +10,8 @@ trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for t in range(trials):
-    Nx = 2 * int(rng.integers(1, 200)); Ny = int(rng.integers(2, 121))
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    Nx = 2 * int(rng.integers(1, 900 if big else 200)); Ny = int(rng.integers(2, 500 if big else 121))
     Hx = int(rng.integers(1, min(Nx, 6) + 1)); Hy = int(rng.integers(1, min(Ny, 6) + 1))
     kw = dict(size=(Nx, Ny, 1), halo=(Hx, Hy, 1), north_poles_latitude=float(np.round(rng.uniform(20, 88), int(rng.integers(0, 6)))),
               first_pole_longitude=float(np.round(rng.uniform(-200, 380), int(rng.integers(0, 6)))),
