@@ -212,7 +212,9 @@ def main():
         if marks is not None: marks[2].record()
         side_stream.wait_stream(main_stream)
         with torch.cuda.stream(side_stream):
+            if marks is not None: marks[4].record()                     # side stream: exchange start / end
             exchange_y_halos(band_fields, arch, transport=transport)
+            if marks is not None: marks[5].record()
         _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
         if marks is not None: marks[3].record()
         main_stream.wait_stream(side_stream)
@@ -252,7 +254,7 @@ def main():
         step(None, zevs[k])
     sync()
     elapsed = time.perf_counter() - t0
-    marks = [[ev() for _ in range(4)] for _ in range(args.steps)]
+    marks = [[ev() for _ in range(6)] for _ in range(args.steps)]
     for k in range(args.steps):
         step(marks[k], None)
     sync()
@@ -262,8 +264,14 @@ def main():
         elapsed = float(t.item())
 
     avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)      # ms
-    if world > 1:      # overlapped step: marks are [start, zipper, periodic, build end]
+    t_exchange = None
+    if world > 1:      # overlapped step: marks are [start, zipper, periodic, build end, exchange start, exchange end]
         t_zip_bracket, t_rest, t_build = avg(0, 1), avg(1, 2), avg(2, 3)
+        if overlap:
+            t_exchange = avg(4, 5)                                      # pack + send/recv + unpack on the side stream
+            te = torch.tensor([t_exchange], dtype=torch.float64, device=None if rehearse else dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)                   # the slowest rank's seams
+            t_exchange = float(te.item())
     else:
         t_build, t_zip_bracket, t_rest = avg(0, 1), avg(1, 2), avg(2, 3)
     t_zip = t_zip_bracket
@@ -301,6 +309,8 @@ def main():
             "precompute_ms": t_build, "zipper_ms": t_zip, "zipper_bracket_ms": t_zip_bracket,
             "periodic_x_ms" if world > 1 else "periodic_and_exchange_ms": t_rest,
             "overlap": "seam exchange on a side stream, concurrent with the grid build" if overlap else None,
+            "exchange_ms": t_exchange,                                  # max over ranks; per seam direction: 4 fields x 9.58 MB
+            "seam_GBps_per_direction": (4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8 / (t_exchange * 1e-3) / 1e9) if t_exchange else None,
             "zipper_GBps": zbytes / (t_zip * 1e-3) / 1e9,
         }
         traffic = None
