@@ -243,6 +243,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Device wake-up (part of the setup, not of the W warm-up steps): after the idle seconds of imports and
+    # allocation the GPU needs ~30 ms of sustained work before its clocks settle; measured per step: 0.64 ms
+    # right after idle, 0.57-0.58 ms from ~50 steps on and in 5000-step runs.  Reported as "prewarm_steps".
+    PREWARM = 48
+    for _ in range(PREWARM):
+        step()
+    sync()
     for _ in range(args.warmup):
         step()
     sync()
@@ -300,7 +307,7 @@ def main():
         line = {
             "metric": "grid-cells/s metric precompute + zipper halo-fill GB/s, 1/10°×75z",
             "value": cells / (elapsed / args.steps), "unit": "cells/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "TripolarGrid 1/10deg metric precompute (3600x1800 per rank, Float64, halo 4) + "
                                    "fill_halo_regions! of 4 fields c/u/v/zeta (3600x1800x75 per rank): zipper + periodic-x"
