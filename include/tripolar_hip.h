@@ -22,14 +22,15 @@
  *    i.e. exactly the `parent` of Oceananigans' OffsetArrays.
  *  - element type selected by `ft`: TPG_F32 or TPG_F64.
  *
- * Tuning / cross-check knobs (environment, read per call; every setting gives identical results --
- * tests/test_gpu_variants.py -- and none is needed in production):
- *    TPG_CELLS_VARIANT   cell kernel of tpg_build_grid: 3 LDS tile (default), 2 / 1 marching waves,
- *                        0 thread per cell
+ * Tuning / cross-check knobs (environment; read ONCE, at the first call into the library, into an immutable
+ * record -- tpg_reload_config() re-reads them; every setting gives identical results,
+ * tests/test_gpu_variants.py, and none is needed in production):
+ *    TPG_CELLS_VARIANT   cell kernel of tpg_build_grid: 3 LDS tile (default), 0 thread per cell (cross-check)
  *    TPG_BUILD_NT        1 streaming stores in tpg_build_grid (default), 0 plain stores
- *    TPG_CELLS_STRIP, TPG_CELLS_CAPACITY   strip sizing of the marching variants
- *    TPG_ZIPPER_VARIANT  0..4: row / column work items, streaming loads / stores (default 3)
+ *    TPG_ZIPPER_VARIANT  3 column work items (default), 0 row work items (the fallback kernels, everywhere)
  *    TPG_FILL_FUSED      0 never / 1 always (where valid) use the fused small-field fill
+ * The library holds no other mutable global state: a thread-local error string, the immutable knob record,
+ * and the lazily bound librccl entry points (std::call_once).
  */
 #ifndef TRIPOLAR_HIP_H
 #define TRIPOLAR_HIP_H
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TPG_VERSION 100 /* 0.1.0 */
+#define TPG_VERSION 200 /* 0.2.0 */
 
 enum tpg_status {
     TPG_OK = 0,
@@ -50,8 +51,9 @@ enum tpg_status {
     TPG_ERR_BAD_PARTITION = -3,    /* row band outside 1..Ny (src/distributed_tripolar_grid.jl:28-49) */
     TPG_ERR_WORKSPACE = -4,        /* workspace missing or too small                              */
     TPG_ERR_UNSUPPORTED = -5,      /* size outside what the kernels index (see tpg_limits)        */
-    TPG_ERR_NOT_NORTH = -6         /* zipper requested on a non-north side
+    TPG_ERR_NOT_NORTH = -6,        /* zipper requested on a non-north side
                                       (src/zipper_boundary_condition.jl:58-62)                    */
+    TPG_ERR_RCCL = -7              /* librccl missing, or an ncclResult_t error (see tpg_last_error) */
 };
 
 enum tpg_ft { TPG_F32 = 0, TPG_F64 = 1 };
@@ -87,6 +89,7 @@ typedef struct tpg_params {
 int tpg_version(void);
 const char *tpg_last_error(void);
 const char *tpg_status_string(int status);
+int tpg_reload_config(void); /* re-read the TPG_* knobs (tests; not for use while other threads are in the library) */
 
 /* ---- metric precompute ------------------------------------------------------------------
  * Replaces, in one call, src/tripolar_grid.jl:73-328: the 1-D tables (:76-97),
@@ -129,6 +132,13 @@ int tpg_zipper_fill_timed(void *const fields[], int nfields,
                           int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
                           int kstart, int kcount, int ft, void *stream,
                           void *start_event, void *stop_event);
+/* Same-shape copy ceiling of the fold (bench.py `zipper_copy_ceiling_ms`): the launch of tpg_zipper_fill over
+ * k = 1..Nz with identical rows, bytes and work decomposition, but destination column = source column and no
+ * sign -- what a pure copy of the fold's bytes costs on this device.  OVERWRITES the north halo rows (and the
+ * east half of row Ny of y-Center fields) with unfolded copies: benchmark use only.  No reference counterpart. */
+int tpg_zipper_copy_probe(void *const fields[], int nfields, const int8_t yloc[],
+                          int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream,
+                          void *start_event, void *stop_event);
 int tpg_event_create(void **event);
 int tpg_event_destroy(void *event);
 int tpg_event_elapsed_ms(void *start_event, void *stop_event, float *ms); /* waits for stop_event */
@@ -152,8 +162,8 @@ int tpg_fill_halo_regions(void *const fields[], int nfields,
 /* ---- latitude-band halo exchange helpers (config 4) -------------------------------------
  * The interior seams of a y-slab partition exchange Hy full rows (all i incl. x halos, all
  * levels incl. z halos) per side and field; the transport (RCCL send/recv, ROCm-aware MPI) stays
- * with the host, as it does in the reference (Oceananigans DistributedComputations, reached from
- * src/distributed_tripolar_grid.jl:171,195).  These two kernels gather / scatter the rows
+ * with the host or with tpg_halo_exchange_y below, as it stays with Oceananigans DistributedComputations in
+ * the reference (reached from src/distributed_tripolar_grid.jl:171,195).  These two kernels gather / scatter the rows
  * between the padded 3-D fields and one contiguous message buffer of
  * nfields * (Nx+2Hx) * Hy * (Nz+2Hz) elements.
  * side: 0 = south, 1 = north.  pack reads the INTERIOR rows adjacent to that side
@@ -166,6 +176,50 @@ int tpg_pack_y_halo(void *const fields[], int nfields, void *buffer, int side,
 int tpg_unpack_y_halo(void *const fields[], int nfields, const void *buffer, int side,
                       int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
 
+/* ---- y-seam exchange over RCCL (config 4) ---------------------------------------------------
+ * fill_halo_regions! of a Field on a DistributedTripolarGrid hands its south / north sides to Oceananigans'
+ * halo communication (src/distributed_tripolar_grid.jl:171 inject_halo_communication_boundary_conditions, :195
+ * FieldBoundaryBuffers; MPI Isend/Irecv of one packed buffer per side [recalled]).  Here one call issues the whole
+ * seam exchange of `nfields` fields of one geometry on `stream`: ONE ncclGroupStart/ncclGroupEnd of point-to-point
+ * ncclSend/ncclRecv (RCCL over xGMI), no host wait, no collective, capturable in a HIP graph.
+ *   comm            ncclComm_t of the latitude-band chain (as void*): created by the host's RCCL binding, or by
+ *                   tpg_comm_init_rank below (librccl is bound lazily with dlopen; TPG_ERR_RCCL if absent).
+ *   rank, nranks    position in the chain: rank 0 is the southernmost band and has no south seam, rank nranks-1
+ *                   owns the zipper and has no north seam (src/distributed_tripolar_grid.jl:75,143-147).
+ *   send_* / recv_* message buffers of tpg_y_halo_buffer_elems(...) elements each (sides without a peer may be
+ *                   NULL): PACKED exchange = tpg_pack_y_halo -> one message per direction -> tpg_unpack_y_halo.
+ *                   All four NULL: PACK-FREE exchange -- the Hy seam rows of one (field, level) are one contiguous
+ *                   window of the parent array (Hy * (Nx+2Hx) elements), sent from / received into the fields
+ *                   directly, (nfields * (Nz+2Hz)) send/recv pairs per direction inside the one group.
+ * Call it after the zipper (north rank) and the periodic-x pass of the same fill, as the reference orders them.
+ * tpg_halo_exchange_y_peers is the same with explicit peer ranks (-1 = no seam on that side). */
+#define TPG_COMM_ID_BYTES 128
+int tpg_comm_unique_id(void *id128);                                             /* ncclGetUniqueId     */
+int tpg_comm_init_rank(void **comm, int nranks, const void *id128, int rank);    /* ncclCommInitRank on the current device */
+int tpg_comm_destroy(void *comm);                                                /* ncclCommDestroy     */
+int tpg_halo_exchange_y(void *comm, int rank, int nranks, void *const fields[], int nfields,
+                        void *send_south, void *send_north, void *recv_south, void *recv_north,
+                        int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
+int tpg_halo_exchange_y_peers(void *comm, int south_peer, int north_peer, void *const fields[], int nfields,
+                              void *send_south, void *send_north, void *recv_south, void *recv_north,
+                              int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
+
+/* ---- geometry utilities over the grid arrays -------------------------------
+ * tpg_nonorthogonality_angle: compute_nonorthogonality_angle! of test/test_tripolar_grid.jl:8-34 as launched at
+ * :70 over (Nx-1, Ny-1): angle[i,j] = rad2deg(acos(v1.v2 / (|v1||v2|)) - pi/2) with v1, v2 the chords from the
+ * Face-Face node (i,j) to (i+1,j) and (i,j+1) on the unit sphere; 0 where immersed[i,j] != 0 and for i = Nx or
+ * j = Ny.  lambda_ff / phi_ff: padded 2-D grid arrays (type `ft`); immersed: dense Nx x Ny bytes or NULL;
+ * angle: dense Nx x Ny Float64, i fastest (the reference's zeros(size(grid)...)).
+ * tpg_convert_frame: convert_to_latlong_frame (to_native = 0) / convert_to_native_frame (to_native = 1) of
+ * examples/convert_to_latlong_frame.jl:12-55 for every interior (i, j, k): rotation of (u, v) by the local
+ * direction cosines d1, d2 derived from phi_cf, phi_fc, dy_cc, dx_cc.  u, v, u_out, v_out: padded 3-D
+ * (Center, Center, Center) parents (only the interior of the outputs is written; outputs may alias nothing). */
+int tpg_nonorthogonality_angle(const void *lambda_ff, const void *phi_ff, const uint8_t *immersed, double *angle,
+                               int Nx, int Ny, int Hx, int Hy, int ft, void *stream);
+int tpg_convert_frame(const void *phi_cf, const void *phi_fc, const void *dy_cc, const void *dx_cc,
+                      const void *u, const void *v, void *u_out, void *v_out, int to_native,
+                      int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
+
 /* Deterministic synthetic field fill used by tests and bench.py:
  * interior (i,j,k) gets a splitmix64(seed, linear index) value in (-1,1); every halo cell gets
  * `halo_sentinel`.  Not part of the reference surface. */
@@ -174,7 +228,7 @@ int tpg_fill_synthetic(void *field, uint64_t seed, double halo_sentinel,
 
 /* Validation hook (tests/test_gpu_math.py): evaluates one of the library's deterministic Float64
  * elementary functions (which = 0 sin, 1 cos, 2 sind, 3 cosd, 4 tand, 5 atan, 6 asin, 7 asinh, 8 sinh,
- * 9 cosh; 20 sqrt_nr(x), 21 div_nr over pairs x = (a0, b0, a1, b1, ...): the unscaled square root and
+ * 9 cosh, 10 acos; 20 sqrt_nr(x), 21 div_nr over pairs x = (a0, b0, a1, b1, ...): the unscaled square root and
  * division of the metric kernel) or one of the straight-line batch forms used by the metric kernel (100 sin_small, 101 cos,
  * 102 atan, 103 atan_tab, 104 atan_small, 105 asin_small, 106 sind / 107 cosd of sincosd) on n device
  * doubles x -> y; rare[i] (int32) = 1 where a batch form reports "outside my fast domain".

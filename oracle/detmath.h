@@ -32,6 +32,7 @@
 /* ---------------------------------------------------------------- constants (gen_constants.py) */
 #define DM_PI        0x1.921fb54442d18p+1
 #define DM_DEG2RAD   0x1.1df46a2529d39p-6   /* Float64(pi)/180, Julia deg2rad */
+#define DM_RAD2DEG   0x1.ca5dc1a63c1f8p+5    /* 180/Float64(pi), Julia rad2deg */
 #define DM_D2R_LO    0x1.5c1d8becdd291p-62  /* pi/180 - DM_DEG2RAD */
 #define DM_INVPIO2   0x1.45f306dc9c883p-1
 #define DM_PIO2_1    0x1.921fb54400000p+0
@@ -252,6 +253,29 @@ DM_INLINE double dm_asin(double x)
         res = DM_PIO4_HI - (p - q);
     }
     return copysign(res, x);
+}
+
+/* ---------------------------------------------------------------- acos (msun e_acos.c; p/q of asin)
+ * used by the non-orthogonality diagnostic (test/test_tripolar_grid.jl:29) only */
+DM_INLINE double dm_acos(double x)
+{
+    double ax = fabs(x);
+    if (ax >= 1.0) {
+        if (ax == 1.0) return x > 0.0 ? 0.0 : DM_PI;
+        return (x - x) / (x - x);                         /* NaN */
+    }
+    if (ax < 0.5) {
+        if (ax < 0x1p-54) return DM_PIO2_HI;
+        double z = x * x;
+        return DM_PIO2_HI - (x - (DM_PIO2_LO - x * dm_asin_pq(z)));
+    }
+    double z = (1.0 - ax) * 0.5;
+    double r = dm_asin_pq(z);
+    double s = sqrt(z);
+    if (x < 0.0) return DM_PI - 2.0 * (s + (r * s - DM_PIO2_LO));
+    double f = dm_from_bits(dm_bits(s) & 0xffffffff00000000ull);
+    double c = (z - f * f) / (s + f);
+    return 2.0 * (f + (r * s + c));
 }
 
 /* ---------------------------------------------------------------- double-double toolkit

@@ -60,6 +60,8 @@ def lib():
             f.restype = C.c_int
         _lib.tpo_periodic_x_fill.argtypes = [C.c_void_p] + [C.c_int] * 7
         _lib.tpo_fill_halo_regions.argtypes = [C.c_void_p] + [C.c_int] * 10
+        _lib.tpo_nonorthogonality_angle.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5
+        _lib.tpo_convert_frame.argtypes = [C.c_void_p] * 8 + [C.c_int] * 8
         _lib.tpo_math_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long]
         _lib.tpo_math_probe.restype = None
         _lib.tpo_tables.argtypes = [C.POINTER(Params)] + [C.c_void_p] * 4
@@ -141,8 +143,32 @@ def fill_halo_regions(field, xloc, yloc, sign, size, halo):
     return field
 
 
+def nonorthogonality_angle(lam_ff, phi_ff, size, halo, immersed=None):
+    """compute_nonorthogonality_angle! over (Nx-1, Ny-1) (test/test_tripolar_grid.jl:8-34,70) -> (Ny, Nx) Float64"""
+    (Nx, Ny, _), (Hx, Hy, _) = size, halo
+    assert lam_ff.shape == (Ny + 2 * Hy, Nx + 2 * Hx) and lam_ff.dtype == phi_ff.dtype and lam_ff.flags.c_contiguous
+    angle = np.empty((Ny, Nx), dtype=np.float64)
+    mask = None if immersed is None else np.ascontiguousarray(immersed, dtype=np.uint8)
+    lib().tpo_nonorthogonality_angle(lam_ff.ctypes.data, phi_ff.ctypes.data, None if mask is None else mask.ctypes.data,
+                                     angle.ctypes.data, Nx, Ny, Hx, Hy, _ft(lam_ff))
+    return angle
+
+
+def convert_frame(grid, u, v, size, halo, to_native=False):
+    """convert_to_latlong_frame / convert_to_native_frame (examples/convert_to_latlong_frame.jl:12-55) on the interior of
+    two padded (Center, Center, Center) parents; grid: dict of the padded 2-D arrays.  Returns (u_out, v_out), zero outside
+    the interior."""
+    (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
+    _check_field(u, Nx, Ny, Nz, Hx, Hy, Hz); _check_field(v, Nx, Ny, Nz, Hx, Hy, Hz)
+    uo, vo = np.zeros_like(u), np.zeros_like(v)
+    g = [np.ascontiguousarray(grid[n], dtype=u.dtype) for n in ("phi_cf", "phi_fc", "dy_cc", "dx_cc")]
+    lib().tpo_convert_frame(*[a.ctypes.data for a in g], u.ctypes.data, v.ctypes.data, uo.ctypes.data, vo.ctypes.data,
+                            1 if to_native else 0, Nx, Ny, Nz, Hx, Hy, Hz, _ft(u))
+    return uo, vo
+
+
 MATH_FUNCS = {"sin": 0, "cos": 1, "sind": 2, "cosd": 3, "tand": 4, "atan": 5, "asin": 6,
-              "asinh": 7, "sinh": 8, "cosh": 9}
+              "asinh": 7, "sinh": 8, "cosh": 9, "acos": 10}
 
 
 def math_probe(name, x):

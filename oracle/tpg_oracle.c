@@ -499,9 +499,84 @@ void tpo_math_probe(int which, const double *x, double *y, long n)
         case 7: y[t] = dm_asinh(v); break;
         case 8: dm_sinh_cosh(v, &s, &c); y[t] = s; break;
         case 9: dm_sinh_cosh(v, &s, &c); y[t] = c; break;
+        case 10: y[t] = dm_acos(v); break;
         default: y[t] = 0.0;
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * SURVEY 8(f-4) geometry utilities.
+ *
+ * compute_nonorthogonality_angle! (test/test_tripolar_grid.jl:8-34), launched over (Nx-1, Ny-1) (:70):
+ *   P = cartesian FF node (get_cartesian_nodes_and_vertices(grid, Face(), Face(), Center()) [recalled]: the unit
+ *   vector lat_lon_to_cartesian(phi, lambda, 1)); v1 = P[i+1,j] - P[i,j]; v2 = P[i,j+1] - P[i,j];
+ *   cos = dot(v1, v2) / (norm(v1) * norm(v2)); angle = rad2deg(ifelse(immersed, pi/2, acos(cos)) - pi/2).
+ * dot / norm of 3-tuples [recalled, LinearAlgebra generic]: left-to-right sums, norm = sqrt(sum of squares).
+ * lam_ff / phi_ff: padded (Nx+2Hx) x (Ny+2Hy) arrays of the grid's FT; angle: dense Nx x Ny Float64, i fastest
+ * (zeros(size(grid)...), :64: entries with i = Nx or j = Ny stay 0); immersed: dense Nx x Ny bytes or NULL.
+ * ------------------------------------------------------------------------------------------ */
+static double ldft(const void *a, size_t idx, int ft) { return ft == 0 ? (double)((const float *)a)[idx] : ((const double *)a)[idx]; }
+
+int tpo_nonorthogonality_angle(const void *lam_ff, const void *phi_ff, const unsigned char *immersed, double *angle,
+                               int Nx, int Ny, int Hx, int Hy, int ft)
+{
+    const size_t sx = (size_t)Nx + 2 * Hx;
+    for (size_t n = 0; n < (size_t)Nx * Ny; ++n) angle[n] = 0.0;
+    for (int j = 1; j <= Ny - 1; ++j)
+        for (int i = 1; i <= Nx - 1; ++i) {
+            size_t c = (size_t)(i + Hx - 1) + sx * (size_t)(j + Hy - 1);
+            vec3 p0 = lat_lon_to_cartesian(ldft(phi_ff, c, ft), ldft(lam_ff, c, ft));
+            vec3 p1 = lat_lon_to_cartesian(ldft(phi_ff, c + 1, ft), ldft(lam_ff, c + 1, ft));
+            vec3 p2 = lat_lon_to_cartesian(ldft(phi_ff, c + sx, ft), ldft(lam_ff, c + sx, ft));
+            vec3 v1 = { p1.x - p0.x, p1.y - p0.y, p1.z - p0.z };                    /* :23 */
+            vec3 v2 = { p2.x - p0.x, p2.y - p0.y, p2.z - p0.z };                    /* :24 */
+            double n1 = sqrt(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z);
+            double n2 = sqrt(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z);
+            double cs = dot3(v1, v2) / (n1 * n2);                                   /* :27 */
+            size_t o = (size_t)(i - 1) + (size_t)Nx * (size_t)(j - 1);
+            int imm = immersed ? immersed[o] != 0 : 0;
+            double a = (imm ? DM_PIO2_HI : dm_acos(cs)) - DM_PIO2_HI;               /* :29 */
+            angle[o] = a * DM_RAD2DEG;                                              /* :32 */
+        }
+    return 0;
+}
+
+/* convert_to_latlong_frame / convert_to_native_frame (examples/convert_to_latlong_frame.jl:12-55), for every
+ * (i, j, k) of the interior, in the grid's FT:
+ *   ut = deg2rad(phi_cf[i,j+1] - phi_cf[i,j]) / dy_cc[i,j];  vt = -deg2rad(phi_fc[i+1,j] - phi_fc[i,j]) / dx_cc[i,j]
+ *   U = sqrt(ut^2 + vt^2); d1 = ut / U; d2 = vt / U
+ *   to lat-lon: (u d1 - v d2, u d2 + v d1)      to native: (u d1 + v d2, u d2 - v d1)
+ * grid arrays padded 2-D, u/v/out padded 3-D (Center, Center, Center) parents; only the interior of out is written. */
+#define DEFINE_FRAME(T, SUF, SQRT, D2R)                                                                     \
+static void convert_frame_##SUF(const T *phi_cf, const T *phi_fc, const T *dy_cc, const T *dx_cc,          \
+                                const T *u, const T *v, T *uo, T *vo, int to_native, const dims_t *d)      \
+{                                                                                                           \
+    for (int k = 1; k <= d->Nz; ++k)                                                                        \
+        for (int j = 1; j <= d->Ny; ++j)                                                                    \
+            for (int i = 1; i <= d->Nx; ++i) {                                                              \
+                size_t c2 = (size_t)(i + d->Hx - 1) + (size_t)d->sx * (size_t)(j + d->Hy - 1);              \
+                size_t c3 = IDX(d, i, j, k);                                                                \
+                T ut = ((phi_cf[c2 + d->sx] - phi_cf[c2]) * (T)(D2R)) / dy_cc[c2];                          \
+                T vt = -((phi_fc[c2 + 1] - phi_fc[c2]) * (T)(D2R)) / dx_cc[c2];                             \
+                T U = SQRT(ut * ut + vt * vt);                                                              \
+                T d1 = ut / U, d2 = vt / U;                                                                 \
+                T a = u[c3], b = v[c3];                                                                     \
+                if (to_native) { uo[c3] = a * d1 + b * d2; vo[c3] = a * d2 - b * d1; }                      \
+                else           { uo[c3] = a * d1 - b * d2; vo[c3] = a * d2 + b * d1; }                      \
+            }                                                                                               \
+}
+DEFINE_FRAME(double, f64, sqrt, DM_DEG2RAD)
+DEFINE_FRAME(float, f32, sqrtf, (float)DM_DEG2RAD)
+
+int tpo_convert_frame(const void *phi_cf, const void *phi_fc, const void *dy_cc, const void *dx_cc,
+                      const void *u, const void *v, void *uo, void *vo, int to_native,
+                      int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft)
+{
+    dims_t d = mkdims(Nx, Ny, Nz, Hx, Hy, Hz);
+    if (ft == 1) convert_frame_f64(phi_cf, phi_fc, dy_cc, dx_cc, u, v, uo, vo, to_native, &d);
+    else         convert_frame_f32(phi_cf, phi_fc, dy_cc, dx_cc, u, v, uo, vo, to_native, &d);
+    return 0;
 }
 
 /* per-j stretching table probe (sinh psi, cosh psi at Face and Center rows) */

@@ -16,6 +16,7 @@ from .grids import (CPU, GPU, Distributed, Partition, OrthogonalSphericalShellGr
                     PeriodicTopology)
 from .fields import (CenterField, Field, HaloFillPlan, XFaceField, YFaceField, ZFaceField, fill_halo_regions,
                      halo_fill_plan, interior, set_)
-from .distributed import exchange_plan, exchange_y_halos, torch_distributed_transport
+from .distributed import (LoopbackMailbox, PendingExchange, RcclComm, exchange_plan, exchange_y_halos, torch_distributed_transport)
+from .geometry import convert_to_latlong_frame, convert_to_native_frame, nonorthogonality_angle
 
 __all__ = ["TripolarGrid", "ZipperBoundaryCondition"]

@@ -24,8 +24,9 @@ ARRAY_NAMES = (
 
 STATUS = {
     0: "TPG_OK", -1: "TPG_ERR_INVALID_ARGUMENT", -2: "TPG_ERR_ODD_NLAMBDA", -3: "TPG_ERR_BAD_PARTITION",
-    -4: "TPG_ERR_WORKSPACE", -5: "TPG_ERR_UNSUPPORTED", -6: "TPG_ERR_NOT_NORTH",
+    -4: "TPG_ERR_WORKSPACE", -5: "TPG_ERR_UNSUPPORTED", -6: "TPG_ERR_NOT_NORTH", -7: "TPG_ERR_RCCL",
 }
+TPG_COMM_ID_BYTES = 128
 
 
 class TpgParams(C.Structure):
@@ -54,12 +55,14 @@ SIGNATURES = {
     "tpg_version": (_i, []),
     "tpg_last_error": (C.c_char_p, []),
     "tpg_status_string": (C.c_char_p, [_i]),
+    "tpg_reload_config": (_i, []),
     "tpg_build_grid_workspace_bytes": (_sz, [C.POINTER(TpgParams)]),
     "tpg_build_grid": (_i, [C.POINTER(TpgParams), C.POINTER(_vp), _vp, _sz, _vp]),
     "tpg_zipper_fill": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
                         + _geom + [_i, _i, _i, _vp]),
     "tpg_zipper_fill_timed": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
                               + _geom + [_i, _i, _i, _vp, _vp, _vp]),
+    "tpg_zipper_copy_probe": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8)] + _geom + [_i, _vp, _vp, _vp]),
     "tpg_event_create": (_i, [C.POINTER(_vp)]),
     "tpg_event_destroy": (_i, [_vp]),
     "tpg_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
@@ -69,6 +72,13 @@ SIGNATURES = {
     "tpg_y_halo_buffer_elems": (_sz, [_i] * 6),
     "tpg_pack_y_halo": (_i, [C.POINTER(_vp), _i, _vp, _i] + _geom + [_i, _vp]),
     "tpg_unpack_y_halo": (_i, [C.POINTER(_vp), _i, _vp, _i] + _geom + [_i, _vp]),
+    "tpg_comm_unique_id": (_i, [_vp]),
+    "tpg_comm_init_rank": (_i, [C.POINTER(_vp), _i, _vp, _i]),
+    "tpg_comm_destroy": (_i, [_vp]),
+    "tpg_halo_exchange_y": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, _vp, _vp, _vp, _vp] + _geom + [_i, _vp]),
+    "tpg_halo_exchange_y_peers": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, _vp, _vp, _vp, _vp] + _geom + [_i, _vp]),
+    "tpg_nonorthogonality_angle": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tpg_convert_frame": (_i, [_vp] * 8 + [_i] + _geom + [_i, _vp]),
     "tpg_fill_synthetic": (_i, [_vp, C.c_uint64, C.c_double] + _geom + [_i, _vp]),
     "tpg_math_probe": (_i, [_i, _vp, _vp, _vp, C.c_longlong, _vp]),
 }

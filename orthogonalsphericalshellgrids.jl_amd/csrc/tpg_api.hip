@@ -1,6 +1,9 @@
 // tpg_api.hip -- version / error channel / argument validation of libtripolar_hip.
 #include "tpg_common.hpp"
 #include <string.h>
+#include <stdlib.h>
+#include <atomic>
+#include <mutex>
 
 namespace tpg {
 
@@ -12,6 +15,37 @@ void set_error(const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+static std::atomic<const Config*> g_config{nullptr};
+static std::mutex g_config_mutex;
+
+static int env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+static const Config* read_config()
+{
+    Config* c = new Config;         // a few bytes per (re)load, never freed: readers may still hold the old record
+    c->cells_variant = env_int("TPG_CELLS_VARIANT", 3) == 0 ? 0 : 3;
+    c->build_nt = env_int("TPG_BUILD_NT", 1) != 0;
+    c->zipper_variant = env_int("TPG_ZIPPER_VARIANT", 3) == 0 ? 0 : 3;
+    c->fill_fused = env_int("TPG_FILL_FUSED", -1);
+    c->fill_merged = env_int("TPG_FILL_MERGED", -1);
+    return c;
+}
+
+const Config& config()
+{
+    const Config* c = g_config.load(std::memory_order_acquire);
+    if (!c) {
+        std::lock_guard<std::mutex> lock(g_config_mutex);
+        c = g_config.load(std::memory_order_acquire);
+        if (!c) { c = read_config(); g_config.store(c, std::memory_order_release); }
+    }
+    return *c;
 }
 
 int check_geom(int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft)
@@ -43,6 +77,13 @@ extern "C" {
 
 int tpg_version(void) { return TPG_VERSION; }
 
+int tpg_reload_config(void)
+{
+    std::lock_guard<std::mutex> lock(tpg::g_config_mutex);
+    tpg::g_config.store(tpg::read_config(), std::memory_order_release);
+    return TPG_OK;
+}
+
 const char* tpg_last_error(void) { return tpg::g_err; }
 
 const char* tpg_status_string(int status)
@@ -55,6 +96,7 @@ const char* tpg_status_string(int status)
     case TPG_ERR_WORKSPACE: return "workspace missing or too small";
     case TPG_ERR_UNSUPPORTED: return "unsupported size";
     case TPG_ERR_NOT_NORTH: return "Zipper boundary condition is valid on the north side only";
+    case TPG_ERR_RCCL: return "RCCL error (librccl missing or ncclResult_t failure)";
     default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown status";
     }
 }

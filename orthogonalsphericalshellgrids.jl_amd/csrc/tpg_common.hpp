@@ -42,4 +42,15 @@ inline Geom make_geom(int Nx, int Ny, int Nz, int Hx, int Hy, int Hz)
 
 int check_geom(int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft);
 
+// Tuning / cross-check knobs (include/tripolar_hip.h): read from the environment ONCE, at the first call into
+// the library, into an immutable record; tpg_reload_config() (tests) publishes a fresh record atomically.
+struct Config {
+    int cells_variant;   // TPG_CELLS_VARIANT  3 LDS-tile kernel (default), 0 thread-per-cell cross-check
+    bool build_nt;       // TPG_BUILD_NT       1 streaming stores in tpg_build_grid (default), 0 plain
+    int zipper_variant;  // TPG_ZIPPER_VARIANT 3 column items (default), 0 row items (the fallback kernels)
+    int fill_fused;      // TPG_FILL_FUSED     -1 automatic (default), 0 never, 1 wherever valid
+    int fill_merged;     // TPG_FILL_MERGED    -1 automatic (default), 0 never, 1 wherever valid
+};
+const Config& config();
+
 }  // namespace tpg

@@ -1,0 +1,188 @@
+// tpg_exchange.hip -- y-seam halo exchange of a latitude-band TripolarGrid over RCCL (xGMI), behind the C ABI.
+//
+// Replaces what a Field on a DistributedTripolarGrid gets from Oceananigans' DistributedComputations
+// (inject_halo_communication_boundary_conditions / FieldBoundaryBuffers, reached from
+// src/distributed_tripolar_grid.jl:171,195): per fill, each interior seam swaps Hy full rows (all i incl. the x
+// halos, all levels incl. the z halos) in both directions.  The reference's transport is MPI Isend/Irecv of one
+// packed buffer per side [recalled]; here it is ONE ncclGroupStart/ncclGroupEnd of point-to-point
+// ncclSend/ncclRecv on the caller's stream: no host wait, no collective (a y-slab chain only talks to its two
+// neighbours), capturable into a HIP graph.  Two message shapes:
+//   packed    : tpg_pack_y_halo -> one message per seam direction ([field][level][Hy][sx], 9.58 MB per field at
+//               1/10 deg x 75 levels) -> tpg_unpack_y_halo;
+//   pack-free : the Hy seam rows of one (field, level) are already one contiguous window of the parent array
+//               (Hy * sx elements = 115 KB at 1/10 deg), so each window is sent from / received into the field
+//               itself: no staging buffers, no pack / unpack kernels, (fields x levels) send/recv pairs per
+//               direction inside the one group.
+// librccl is bound at first use with dlopen (no link-time dependency: a host that never exchanges -- serial grids,
+// this container -- needs no RCCL).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): one seam direction of a
+// 4-field fill is 38.3 MB, i.e. >= 0.25 ms on one link; the two directions use the link's two directions.
+#include "tpg_common.hpp"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <string.h>
+#include <mutex>
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    char why[256] = "";
+};
+
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+void load_rccl()
+{
+    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+    for (const char* n : names) {
+        g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.handle) break;
+    }
+    if (!g_rccl.handle) { snprintf(g_rccl.why, sizeof g_rccl.why, "librccl not found: %s", dlerror()); return; }
+    bool ok = true;
+#define BIND(field, sym)                                                                     \
+    do {                                                                                     \
+        *reinterpret_cast<void**>(&g_rccl.field) = dlsym(g_rccl.handle, sym);               \
+        if (!g_rccl.field) { snprintf(g_rccl.why, sizeof g_rccl.why, "librccl lacks %s", sym); ok = false; } \
+    } while (0)
+    BIND(GetUniqueId, "ncclGetUniqueId"); BIND(CommInitRank, "ncclCommInitRank"); BIND(CommDestroy, "ncclCommDestroy");
+    BIND(CommCount, "ncclCommCount"); BIND(CommUserRank, "ncclCommUserRank");
+    BIND(Send, "ncclSend"); BIND(Recv, "ncclRecv"); BIND(GroupStart, "ncclGroupStart"); BIND(GroupEnd, "ncclGroupEnd");
+    BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+    if (!ok) { dlclose(g_rccl.handle); g_rccl.handle = nullptr; }
+}
+
+const Rccl* rccl()
+{
+    std::call_once(g_rccl_once, load_rccl);
+    if (!g_rccl.handle) { tpg::set_error("%s", g_rccl.why); return nullptr; }
+    return &g_rccl;
+}
+
+int nccl_status(const Rccl* r, ncclResult_t e, const char* what)
+{
+    if (e == ncclSuccess) return TPG_OK;
+    tpg::set_error("%s: %s (ncclResult_t %d)", what, r->GetErrorString(e), (int)e);
+    return TPG_ERR_RCCL;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tpg_comm_unique_id(void* id128)
+{
+    if (!id128) { tpg::set_error("null id buffer"); return TPG_ERR_INVALID_ARGUMENT; }
+    const Rccl* r = rccl();
+    if (!r) return TPG_ERR_RCCL;
+    static_assert(sizeof(ncclUniqueId) == TPG_COMM_ID_BYTES, "ncclUniqueId size");
+    return nccl_status(r, r->GetUniqueId(static_cast<ncclUniqueId*>(id128)), "ncclGetUniqueId");
+}
+
+int tpg_comm_init_rank(void** comm, int nranks, const void* id128, int rank)
+{
+    if (!comm || !id128 || nranks < 1 || rank < 0 || rank >= nranks) { tpg::set_error("bad communicator arguments"); return TPG_ERR_INVALID_ARGUMENT; }
+    const Rccl* r = rccl();
+    if (!r) return TPG_ERR_RCCL;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t c = nullptr;
+    int rc = nccl_status(r, r->CommInitRank(&c, nranks, id, rank), "ncclCommInitRank");
+    *comm = rc ? nullptr : c;
+    return rc;
+}
+
+int tpg_comm_destroy(void* comm)
+{
+    if (!comm) return TPG_OK;
+    const Rccl* r = rccl();
+    if (!r) return TPG_ERR_RCCL;
+    return nccl_status(r, r->CommDestroy(static_cast<ncclComm_t>(comm)), "ncclCommDestroy");
+}
+
+int tpg_halo_exchange_y_peers(void* comm, int south_peer, int north_peer, void* const fields[], int nfields,
+                              void* send_south, void* send_north, void* recv_south, void* recv_north,
+                              int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream)
+{
+    int rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft);
+    if (rc) return rc;
+    if (!comm) { tpg::set_error("null communicator"); return TPG_ERR_INVALID_ARGUMENT; }
+    if (!fields || nfields < 1) { tpg::set_error("no fields"); return TPG_ERR_INVALID_ARGUMENT; }
+    for (int f = 0; f < nfields; ++f) if (!fields[f]) { tpg::set_error("null field %d", f); return TPG_ERR_INVALID_ARGUMENT; }
+    if (nfields > TPG_MAX_FIELDS) { tpg::set_error("at most %d fields per exchange", TPG_MAX_FIELDS); return TPG_ERR_UNSUPPORTED; }
+    if (Hy == 0 || (south_peer < 0 && north_peer < 0)) return TPG_OK;
+    const bool packed = send_south || send_north || recv_south || recv_north;
+    if (packed && ((south_peer >= 0 && (!send_south || !recv_south)) || (north_peer >= 0 && (!send_north || !recv_north)))) {
+        tpg::set_error("packed exchange: a message buffer is missing for a side that has a peer");
+        return TPG_ERR_INVALID_ARGUMENT;
+    }
+    const Rccl* r = rccl();
+    if (!r) return TPG_ERR_RCCL;
+    ncclComm_t c = static_cast<ncclComm_t>(comm);
+    hipStream_t s = tpg::as_stream(stream);
+    const ncclDataType_t dt = ft == TPG_F64 ? ncclFloat64 : ncclFloat32;
+    const size_t esz = ft == TPG_F64 ? 8 : 4;
+    const size_t sx = (size_t)Nx + 2 * Hx, sy = (size_t)Ny + 2 * Hy, nlev = (size_t)Nz + 2 * Hz;
+    const size_t window = (size_t)Hy * sx;                      // elements of one (field, level) seam window
+    const size_t msg = tpg_y_halo_buffer_elems(nfields, Nx, Nz, Hx, Hy, Hz);
+
+    if (packed) {
+        if (north_peer >= 0 && (rc = tpg_pack_y_halo(fields, nfields, send_north, 1, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream))) return rc;
+        if (south_peer >= 0 && (rc = tpg_pack_y_halo(fields, nfields, send_south, 0, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream))) return rc;
+    }
+    // Order inside the group: sends north-then-south, receives from-south-then-from-north, so that a rank whose two
+    // peers are the same rank (a ring of two, or the single-rank loop-back of the tests) pairs "sent north" with
+    // "received from the south".
+    if ((rc = nccl_status(r, r->GroupStart(), "ncclGroupStart"))) return rc;
+    ncclResult_t e = ncclSuccess;
+    auto send_side = [&](int peer, void* buffer, size_t row0) {
+        if (peer < 0 || e != ncclSuccess) return;
+        if (packed) { e = r->Send(buffer, msg, dt, peer, c, s); return; }
+        for (int f = 0; f < nfields && e == ncclSuccess; ++f)
+            for (size_t l = 0; l < nlev && e == ncclSuccess; ++l)
+                e = r->Send(static_cast<const char*>(fields[f]) + (sx * sy * l + sx * row0) * esz, window, dt, peer, c, s);
+    };
+    auto recv_side = [&](int peer, void* buffer, size_t row0) {
+        if (peer < 0 || e != ncclSuccess) return;
+        if (packed) { e = r->Recv(buffer, msg, dt, peer, c, s); return; }
+        for (int f = 0; f < nfields && e == ncclSuccess; ++f)
+            for (size_t l = 0; l < nlev && e == ncclSuccess; ++l)
+                e = r->Recv(static_cast<char*>(fields[f]) + (sx * sy * l + sx * row0) * esz, window, dt, peer, c, s);
+    };
+    send_side(north_peer, send_north, (size_t)Ny);               // interior rows j = Ny-Hy+1..Ny  (parent rows Ny..Ny+Hy-1)
+    send_side(south_peer, send_south, (size_t)Hy);               // interior rows j = 1..Hy
+    recv_side(south_peer, recv_south, 0);                        // halo rows j = 1-Hy..0
+    recv_side(north_peer, recv_north, (size_t)Ny + Hy);          // halo rows j = Ny+1..Ny+Hy
+    ncclResult_t e2 = r->GroupEnd();
+    if ((rc = nccl_status(r, e, "ncclSend/ncclRecv"))) return rc;
+    if ((rc = nccl_status(r, e2, "ncclGroupEnd"))) return rc;
+    if (packed) {
+        if (south_peer >= 0 && (rc = tpg_unpack_y_halo(fields, nfields, recv_south, 0, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream))) return rc;
+        if (north_peer >= 0 && (rc = tpg_unpack_y_halo(fields, nfields, recv_north, 1, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream))) return rc;
+    }
+    return TPG_OK;
+}
+
+int tpg_halo_exchange_y(void* comm, int rank, int nranks, void* const fields[], int nfields,
+                        void* send_south, void* send_north, void* recv_south, void* recv_north,
+                        int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks) { tpg::set_error("rank %d outside 0:%d", rank, nranks - 1); return TPG_ERR_BAD_PARTITION; }
+    // rank 0 is the southernmost band, rank nranks-1 owns the zipper: neither of those two sides communicates
+    return tpg_halo_exchange_y_peers(comm, rank > 0 ? rank - 1 : -1, rank < nranks - 1 ? rank + 1 : -1, fields, nfields,
+                                     send_south, send_north, recv_south, recv_north, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream);
+}
+
+}  // extern "C"

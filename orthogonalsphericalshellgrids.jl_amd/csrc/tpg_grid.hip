@@ -12,7 +12,7 @@
 //                    staggered locations of the cell and of its stencil neighbours THROUGH the halo
 //                    index maps (periodic x, zipper fold, row-Ny substitution, zero south halo),
 //                    then the 8 haversine edge lengths, 2 spherical quadrilateral areas and 2
-//                    product areas; stores 8 + 12 values.  Four forms with identical arithmetic
+//                    product areas; stores 8 + 12 values.  Two forms with identical arithmetic
 //                    (tests/test_gpu_variants.py), selected by TPG_CELLS_VARIANT:
 //                      3  k_cells_tile   DEFAULT.  A block of 8 waves evaluates 8 point rows x 64
 //                                        columns once (one point set per thread), parks them in LDS
@@ -20,13 +20,11 @@
 //                                        its own registers + LDS neighbours.  <= 128 VGPRs: 4
 //                                        waves/SIMD; transcendentals as straight-line batches
 //                                        (tpg_batch.hpp).
-//                      2  k_cells_fast   waves of 62 columns march north over a strip of rows; the
-//                                        point sets of two rows stay in registers (256 VGPRs, 2
-//                                        waves/SIMD) and reach the neighbour lanes by shuffles.
-//                      1  k_cells_march  same marching scheme on the scalar functions; also the
-//                                        path for |first_pole_longitude + 90| > 360 inside (2).
 //                      0  k_cells        one thread per cell, everything recomputed: the simple
-//                                        reference form the others are checked against.
+//                                        reference form the tile kernel is checked against.
+//                    (Round 1 also carried two register-marching forms -- waves of 62 columns marching
+//                    north with the previous row in registers, 256 VGPRs, 2 waves/SIMD: 664-706 us vs the
+//                    tile form's 499 us at 1/10 degree; removed, history in DESIGN.md 4.)
 //   K2 halos       : compact pass over halo cells only (x-halo columns, north fold rows, zero
 //                    south rows of the coordinates, row-Ny substitution of the y-Center metrics).
 //   K3 south       : lat-lon continuation rows j = 1-Hy..1 of the 12 metrics (south rank only).
@@ -36,7 +34,6 @@
 #include "tpg_common.hpp"
 #include "tpg_math.hpp"
 #include "tpg_batch.hpp"
-#include <stdlib.h>
 
 using namespace tpgm;
 
@@ -315,16 +312,12 @@ __global__ __launch_bounds__(256) void k_cells(GridK g, OutPtrs o)
     put<T, NT>(o, TPG_AZ_CF, off, azcf); put<T, NT>(o, TPG_AZ_FF, off, azff);
 }
 
-// ---- K1 (marching form): one wave = 62 output columns x a strip of rows -----------------------
+// ---- shared point records of the work-sharing form (k_cells_tile) ------------------------------------
 // Every staggered point (lambda, phi) and what the metrics derive from it -- a = deg2rad(phi),
 // cos(a) for the haversines, the unit vector for the two quadrilateral areas -- is evaluated ONCE
-// by the lane that owns its column, kept in registers while the wave marches north, and handed to
-// the east / west neighbour lane with wave shuffles (no LDS allocation, no barrier).  Lanes 0 and
-// 63 are apron lanes (they only supply their neighbours), so a wave emits 62 columns.  Compared
-// with the thread-per-cell form this removes the 14 redundant point evaluations per cell and the
-// repeated cos / sind / cosd of shared points: ~65 instead of ~140 transcendental calls per cell.
-// The arithmetic of every value is unchanged (same operation sequence), so results are
-// bit-identical to k_cells.
+// by the thread that owns it and shared with the cells around it: ~65 instead of ~140 transcendental
+// calls per cell.  The arithmetic of every value is unchanged (same operation sequence), so results
+// are bit-identical to k_cells.
 struct Pt  { double lam, phi, a, ca; };                 // FC / CF points
 struct PtX { double lam, phi, a, ca, X, Y, Z; };        // CC / FF points (+ unit vector)
 struct Nb  { double lam, a, ca; };                      // what a haversine needs of a neighbour
@@ -377,81 +370,13 @@ __device__ __forceinline__ double hav(double xlam, double xa, double xca, double
 }
 #define HAV(P, Q) hav((P).lam, (P).a, (P).ca, (Q).lam, (Q).a, (Q).ca, R)
 
-struct MarchArgs { int nwx, L; };
 
-template <typename T, bool NT>
-__global__ __launch_bounds__(256) void k_cells_march(GridK g, OutPtrs o, MarchArgs m)
-{
-    const int lane = threadIdx.x & 63;
-    const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int strip = wv / m.nwx;
-    const int xw = wv - strip * m.nwx;
-    const int jlo = g.jm_lo + strip * m.L;
-    if (jlo > g.jm_hi) return;                                     // whole wave exits together
-    const int jhi = min(jlo + m.L - 1, g.jm_hi);
-    int i = xw * 62 + lane;                                        // lanes 0 / 63: west / east apron
-    const bool emit = lane >= 1 && lane <= 62 && i <= g.Nx;
-    if (i > g.Nx + 1) i = g.Nx + 1;                                // idle lanes of the last window
-    const double R = g.R;
-
-    // prologue: FC, CC on row jlo-1; FF, CF on row jlo
-    Pt fcP = make_pt(g, 1, 0, i, jlo - 1), cfP = make_pt(g, 0, 1, i, jlo);
-    PtX ccP = make_ptx(g, 0, 0, i, jlo - 1), ffP = make_ptx(g, 1, 1, i, jlo);
-    NbX ccWP = shf_nbx<-1>(ccP);                                   // CC(i-1, jlo-1)
-    NbX ffEP = shf_nbx<+1>(ffP);                                   // FF(i+1, jlo)
-    Nb cfWP = shf_nb<-1>(cfP);                                     // CF(i-1, jlo)
-
-    for (int j = jlo; j <= jhi; ++j) {
-        Pt fc = make_pt(g, 1, 0, i, j), cf = make_pt(g, 0, 1, i, j + 1);
-        PtX cc = make_ptx(g, 0, 0, i, j), ff = make_ptx(g, 1, 1, i, j + 1);
-        Nb fcE = shf_nb<+1>(fc);                                   // FC(i+1, j)
-        NbX ccW = shf_nbx<-1>(cc);                                 // CC(i-1, j)
-        NbX ffE = shf_nbx<+1>(ff);                                 // FF(i+1, j+1)
-        Nb cfW = shf_nb<-1>(cf);                                   // CF(i-1, j+1)
-
-        // FC: e = fcE, c = fc, s = fcP | CC: c = cc, w = ccW, s = ccP, sw = ccWP
-        // FF: c = ffP, e = ffEP, n = ff, ne = ffE | CF: c = cfP, w = cfWP, n = cf
-        double dxcc = HAV(fcE, fc);            // tripolar_grid_utils.jl:13
-        double dxfc = HAV(cc, ccW);            // :14
-        double dxcf = HAV(ffEP, ffP);          // :15
-        double dxff = HAV(cfP, cfWP);          // :16
-        double dycc = HAV(cf, cfP);            // :18
-        double dyfc = HAV(ff, ffP);            // :19
-        double dycf = HAV(cc, ccP);            // :20
-        double dyff = HAV(fc, fcP);            // :21
-        double azcc = quad_area(v3_of(ffP), v3_of(ffEP), v3_of(ffE), v3_of(ff)) * (R * R);     // :23-28
-        double azfc = dyfc * dxfc;             // :34
-        double azcf = dycf * dxcf;             // :35
-        double azff = quad_area(v3_of(ccWP), v3_of(ccP), v3_of(cc), v3_of(ccW)) * (R * R);     // :38-43
-
-        if (emit) {
-            long long off = (long long)(i + g.Hx - 1) + (long long)g.sx * (j - g.jstart + g.Hy);
-            put<T, NT>(o, TPG_LAMBDA_CC, off, cc.lam); put<T, NT>(o, TPG_LAMBDA_FC, off, fc.lam);
-            put<T, NT>(o, TPG_LAMBDA_CF, off, cfP.lam); put<T, NT>(o, TPG_LAMBDA_FF, off, ffP.lam);
-            put<T, NT>(o, TPG_PHI_CC, off, cc.phi); put<T, NT>(o, TPG_PHI_FC, off, fc.phi);
-            put<T, NT>(o, TPG_PHI_CF, off, cfP.phi); put<T, NT>(o, TPG_PHI_FF, off, ffP.phi);
-            put<T, NT>(o, TPG_DX_CC, off, dxcc); put<T, NT>(o, TPG_DX_FC, off, dxfc);
-            put<T, NT>(o, TPG_DX_CF, off, dxcf); put<T, NT>(o, TPG_DX_FF, off, dxff);
-            put<T, NT>(o, TPG_DY_CC, off, dycc); put<T, NT>(o, TPG_DY_CF, off, dycf);
-            put<T, NT>(o, TPG_DY_FC, off, dyfc); put<T, NT>(o, TPG_DY_FF, off, dyff);
-            put<T, NT>(o, TPG_AZ_CC, off, azcc); put<T, NT>(o, TPG_AZ_FC, off, azfc);
-            put<T, NT>(o, TPG_AZ_CF, off, azcf); put<T, NT>(o, TPG_AZ_FF, off, azff);
-        }
-        fcP = fc; ccP = cc; ffP = ff; cfP = cf;
-        ccWP = ccW; ffEP = ffE; cfWP = cfW;
-    }
-}
-#undef HAV
-
-// ---- K1 (fast marching form) ---------------------------------------------------------------
-// Same marching scheme as k_cells_march, restructured for FP64 issue efficiency:
+// ---- one point set = the 4 points a tile thread creates, on the straight-line batch forms ----------
 //  * rows j < Ny need no fold / substitution / pole logic, so a lane's lambda-table values
-//    (a sind, a cosd at its Face and Center column) are loop-invariant registers and the per-row
-//    psi-table values are wave-uniform; the index maps of coord() are left to the one special row;
-//  * all transcendentals of a step are evaluated by the straight-line batch forms of
-//    tpg_batch.hpp (4 independent chains per basic block), with rare cases patched afterwards;
-//  * coordinates are stored when computed, so the marching state is (lambda, a, cos a[, X, Y, Z]).
-// Bit-identical to k_cells / k_cells_march (tests/test_gpu_grid.py).
+//    (a sind, a cosd at its Face and Center column) and the per-row psi-table values (wave-uniform)
+//    feed the Murray map directly; the index maps of coord() are left to the special rows;
+//  * all transcendentals are evaluated by the straight-line batch forms of tpg_batch.hpp
+//    (independent chains per basic block), with rare cases patched afterwards.
 struct Step4 {           // the 4 points a step creates: k = 0 FC(jc), 1 CC(jc), 2 FF(jf), 3 CF(jf)
     double lam[4], phi[4], a[4], ca[4];
     double X[2], Y[2], Z[2];     // 0: CC, 1: FF
@@ -557,174 +482,18 @@ __device__ __noinline__ void points_general(const GridK& g, int i, int jc, int j
     s.X[1] = ff.X; s.Y[1] = ff.Y; s.Z[1] = ff.Z;
 }
 
-template <typename T, bool NT>
-__global__ __launch_bounds__(256, 2) void k_cells_fast(GridK g, OutPtrs o, MarchArgs m)
-{
-    __shared__ __attribute__((aligned(16))) double atab[TPG_ATAN_TABLE_DOUBLES];
-    tpgb::atan_table_init(atab, threadIdx.x);
-    __syncthreads();                                               // the only barrier: before any wave can exit
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const int strip = wv / m.nwx;
-    const int xw = wv - strip * m.nwx;
-    const int jlo = g.jm_lo + strip * m.L;
-    if (jlo > g.jm_hi) return;
-    const int jhi = min(jlo + m.L - 1, g.jm_hi);
-    int i = xw * 62 + lane;                                        // lanes 0 / 63: west / east apron
-    const bool emit = lane >= 1 && lane <= 62 && i <= g.Nx;
-    if (i > g.Nx + 1) i = g.Nx + 1;
-    const double R = g.R;
-    const bool small_lon = absD(g.fplp90) <= 360.0;                // |l| < 720 before the wrap
-
-    LaneConst lc;
-    {
-        const int iw = i < 1 ? i + g.Nx : (i > g.Nx ? i - g.Nx : i);
-        int i0 = iw - g.shift; if (i0 < 1) i0 += g.Nx;
-        lc.aslF = g.ti[0 * g.Nx + iw - 1]; lc.aclF = g.ti[1 * g.Nx + iw - 1];
-        lc.aslC = g.ti[2 * g.Nx + iw - 1]; lc.aclC = g.ti[3 * g.Nx + iw - 1];
-        lc.hemi = (i0 <= g.Nx / 2) ? -90.0 : 90.0;
-    }
-    const long long col = (long long)(i + g.Hx - 1);
-    auto rowoff = [&](int j) -> long long { return col + (long long)g.sx * (j - g.jstart + g.Hy); };
-
-    // marching state: previous-row points (own + neighbours)
-    Nb fcP, cfP, cfWP;
-    NbX ccP, ffP, ccWP, ffEP;
-    {
-        Step4 s;
-        // prologue: FC, CC on row jlo-1; FF, CF on row jlo
-        if (jlo - 1 >= 1 && jlo - 1 < g.Ny && small_lon) points_fast(g, lc, load_rowtab(g, jlo - 1, jlo), s, atab);
-        else { Step4 tmp; GridK gc = g; points_general(gc, i, jlo - 1, jlo, tmp); s = tmp; }   // only the copies are address-taken:
-                                                                                          // g itself stays in SGPRs (kernarg)
-        if (emit) {
-            long long off = rowoff(jlo);
-            put<T, NT>(o, TPG_LAMBDA_FF, off, s.lam[2]); put<T, NT>(o, TPG_PHI_FF, off, s.phi[2]);
-            put<T, NT>(o, TPG_LAMBDA_CF, off, s.lam[3]); put<T, NT>(o, TPG_PHI_CF, off, s.phi[3]);
-        }
-        fcP = Nb{ s.lam[0], s.a[0], s.ca[0] };
-        ccP = NbX{ s.lam[1], s.a[1], s.ca[1], s.X[0], s.Y[0], s.Z[0] };
-        ffP = NbX{ s.lam[2], s.a[2], s.ca[2], s.X[1], s.Y[1], s.Z[1] };
-        cfP = Nb{ s.lam[3], s.a[3], s.ca[3] };
-        ccWP = NbX{ shf<-1>(ccP.lam), shf<-1>(ccP.a), shf<-1>(ccP.ca), shf<-1>(ccP.X), shf<-1>(ccP.Y), shf<-1>(ccP.Z) };
-        ffEP = NbX{ shf<+1>(ffP.lam), shf<+1>(ffP.a), shf<+1>(ffP.ca), shf<+1>(ffP.X), shf<+1>(ffP.Y), shf<+1>(ffP.Z) };
-        cfWP = Nb{ shf<-1>(cfP.lam), shf<-1>(cfP.a), shf<-1>(cfP.ca) };
-    }
-
-    RowTab rt = load_rowtab(g, jlo, jlo + 1);
-    for (int j = jlo; j <= jhi; ++j) {
-        Step4 s;
-        const RowTab rt_now = rt;
-        rt = load_rowtab(g, j + 1, j + 2);                         // prefetch the next row's values
-        if (j < g.Ny && small_lon) points_fast(g, lc, rt_now, s, atab);
-        else { Step4 tmp; GridK gc = g; points_general(gc, i, j, j + 1, tmp); s = tmp; }
-        if (emit) {
-            long long off = rowoff(j);
-            put<T, NT>(o, TPG_LAMBDA_FC, off, s.lam[0]); put<T, NT>(o, TPG_PHI_FC, off, s.phi[0]);
-            put<T, NT>(o, TPG_LAMBDA_CC, off, s.lam[1]); put<T, NT>(o, TPG_PHI_CC, off, s.phi[1]);
-            if (j + 1 <= jhi) {
-                long long off1 = off + g.sx;
-                put<T, NT>(o, TPG_LAMBDA_FF, off1, s.lam[2]); put<T, NT>(o, TPG_PHI_FF, off1, s.phi[2]);
-                put<T, NT>(o, TPG_LAMBDA_CF, off1, s.lam[3]); put<T, NT>(o, TPG_PHI_CF, off1, s.phi[3]);
-            }
-        }
-        const Nb fc = Nb{ s.lam[0], s.a[0], s.ca[0] };
-        const NbX cc = NbX{ s.lam[1], s.a[1], s.ca[1], s.X[0], s.Y[0], s.Z[0] };
-        const NbX ff = NbX{ s.lam[2], s.a[2], s.ca[2], s.X[1], s.Y[1], s.Z[1] };
-        const Nb cf = Nb{ s.lam[3], s.a[3], s.ca[3] };
-        const Nb fcE = Nb{ shf<+1>(fc.lam), shf<+1>(fc.a), shf<+1>(fc.ca) };                                        // FC(i+1, j)
-        const NbX ccW = NbX{ shf<-1>(cc.lam), shf<-1>(cc.a), shf<-1>(cc.ca), shf<-1>(cc.X), shf<-1>(cc.Y), shf<-1>(cc.Z) };   // CC(i-1, j)
-        const NbX ffE = NbX{ shf<+1>(ff.lam), shf<+1>(ff.a), shf<+1>(ff.ca), shf<+1>(ff.X), shf<+1>(ff.Y), shf<+1>(ff.Z) };   // FF(i+1, j+1)
-        const Nb cfW = Nb{ shf<-1>(cf.lam), shf<-1>(cf.a), shf<-1>(cf.ca) };                                        // CF(i-1, j+1)
-
-        // ---- 8 haversines (x = first argument, y = second; tripolar_grid_utils.jl:13-21)
-        //      e: 0 dxcc(fcE,fc) 1 dxfc(cc,ccW) 2 dxcf(ffEP,ffP) 3 dxff(cfP,cfWP)
-        //         4 dycc(cf,cfP) 5 dyfc(ff,ffP) 6 dycf(cc,ccP)   7 dyff(fc,fcP)
-        const double xl_[8] = { fcE.lam, cc.lam, ffEP.lam, cfP.lam, cf.lam, ff.lam, cc.lam, fc.lam };
-        const double xa_[8] = { fcE.a, cc.a, ffEP.a, cfP.a, cf.a, ff.a, cc.a, fc.a };
-        const double xc_[8] = { fcE.ca, cc.ca, ffEP.ca, cfP.ca, cf.ca, ff.ca, cc.ca, fc.ca };
-        const double yl_[8] = { fc.lam, ccW.lam, ffP.lam, cfWP.lam, cfP.lam, ffP.lam, ccP.lam, fcP.lam };
-        const double ya_[8] = { fc.a, ccW.a, ffP.a, cfWP.a, cfP.a, ffP.a, ccP.a, fcP.a };
-        const double yc_[8] = { fc.ca, ccW.ca, ffP.ca, cfWP.ca, cfP.ca, ffP.ca, ccP.ca, fcP.ca };
-        double d[8];
-#pragma unroll
-        for (int hb = 0; hb < 8; hb += 4) {          // two groups of 4 independent chains
-            double hp[4], hl[4], s1[4], s2[4], rm[4], as[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                double dl = (yl_[hb + e] - xl_[hb + e]) * kDeg2Rad;
-                double dp = ya_[hb + e] - xa_[hb + e];
-                hp[e] = dp / 2; hl[e] = dl / 2;
-            }
-            if (tpgb::sin_small_b<4>(hp, s1)) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s1[e] = sinD(hp[e]);
-            }
-            if (tpgb::sin_small_b<4>(hl, s2)) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s2[e] = sinD(hl[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                double h = s1[e] * s1[e] + xc_[hb + e] * yc_[hb + e] * (s2[e] * s2[e]);
-                const double r = sqrt_nr(h);              // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles)
-                rm[e] = !(r >= 1.0) ? r : 1.0;        // min(r, 1) with NaN kept: one compare
-            }
-            if (tpgb::asin_small_b<4>(rm, as)) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) as[e] = asinD(rm[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[hb + e] = 2 * (R * as[e]);
-        }
-
-        // ---- 2 spherical quadrilaterals = 8 triangles (:23-28, :38-43)
-        const V3 qa[2] = { v3_of(ffP), v3_of(ccWP) }, qb[2] = { v3_of(ffEP), v3_of(ccP) };
-        const V3 qc[2] = { v3_of(ffE), v3_of(cc) },   qd[2] = { v3_of(ff), v3_of(ccW) };
-        double area[2];
-#pragma unroll
-        for (int qd_ = 0; qd_ < 2; ++qd_) {
-            const V3 a = qa[qd_], b = qb[qd_], c = qc[qd_], dd = qd[qd_];
-            double tt[4], at[4];
-            tt[0] = tri_tan_nr(a, b, c); tt[1] = tri_tan_nr(a, b, dd);
-            tt[2] = tri_tan_nr(a, c, dd); tt[3] = tri_tan_nr(b, c, dd);
-            if (__any(tpgb::atan_small_b<4>(tt, at))) {                 // wave-uniform fallback (large or degenerate triangles)
-                tt[0] = tri_tan(a, b, c); tt[1] = tri_tan(a, b, dd); tt[2] = tri_tan(a, c, dd); tt[3] = tri_tan(b, c, dd);
-                tpgb::atan_b<4>(tt, at);
-            }
-            double A = 2 * at[0];
-            A += 2 * at[1];
-            A += 2 * at[2];
-            A += 2 * at[3];
-            area[qd_] = A / 2;
-        }
-        if (emit) {
-            long long off = rowoff(j);
-            put<T, NT>(o, TPG_DX_CC, off, d[0]); put<T, NT>(o, TPG_DX_FC, off, d[1]);
-            put<T, NT>(o, TPG_DX_CF, off, d[2]); put<T, NT>(o, TPG_DX_FF, off, d[3]);
-            put<T, NT>(o, TPG_DY_CC, off, d[4]); put<T, NT>(o, TPG_DY_FC, off, d[5]);
-            put<T, NT>(o, TPG_DY_CF, off, d[6]); put<T, NT>(o, TPG_DY_FF, off, d[7]);
-            put<T, NT>(o, TPG_AZ_CC, off, area[0] * (R * R));
-            put<T, NT>(o, TPG_AZ_FC, off, d[5] * d[1]);          // :34  dy_fc * dx_fc
-            put<T, NT>(o, TPG_AZ_CF, off, d[6] * d[2]);          // :35  dy_cf * dx_cf
-            put<T, NT>(o, TPG_AZ_FF, off, area[1] * (R * R));
-        }
-        fcP = fc; ccP = cc; ffP = ff; cfP = cf;
-        ccWP = ccW; ffEP = ffE; cfWP = cfW;
-    }
-}
-
 // ---- K1 (tile form): 64 x R point sets per block through LDS, 4 waves per SIMD -------------------
-// The marching kernels need ~70 live doubles per lane (two rows of points + neighbours) and run at 2
-// waves/SIMD, where dependent FP64 chains leave the VALU idle ~28 % of the time (PMC); the plain
-// thread-per-cell kernel at 4 waves/SIMD is 95 % busy.  This form keeps the work-sharing but not the
+// Sharing points through registers (a wave marching north with the previous row live) needs ~70 live doubles
+// per lane: 2 waves/SIMD, where dependent FP64 chains leave the VALU idle ~28 % of the time (PMC, round 1); the
+// plain thread-per-cell kernel at 4 waves/SIMD is 95 % busy.  This form keeps the work-sharing but not the
 // register state: a block of 64 x R threads evaluates one point set per thread (step s = FC(s), CC(s),
-// FF(s+1), CF(s+1), exactly as one marching step), parks {lambda, a, cos a[, X, Y, Z]} in LDS
+// FF(s+1), CF(s+1)), parks {lambda, a, cos a[, X, Y, Z]} in LDS
 // (18 doubles x 64 x R), and after ONE barrier every thread with a south and east/west neighbour
 // inside the tile computes its cell from its own registers plus 48 LDS reads.  Row p = 0 and lanes
 // 0 / 63 are aprons (tiles overlap by one point row / two columns): (R-1)/R x 62/64 of the lanes emit;
 // the apron wave, which has no cell row, spends phase 2 on one of the eight haversines (Dy_ff) of all rows.
 // A wave owns one point row, so the special rows (0, Ny) are a wave-uniform branch to coord().
-// Same arithmetic as the other K1 forms: bit-identical results.
+// Same arithmetic as k_cells: bit-identical results.
 template <int R> struct TileLds { double v[18][R][64]; };
 enum { L_FC = 0, L_CC = 3, L_FF = 9, L_CF = 15 };    // field bases: FC(lam,a,ca) CC(lam,a,ca,X,Y,Z) FF(6) CF(3)
 
@@ -1024,63 +793,18 @@ template <typename T>
 int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStream_t s)
 {
     dim3 grid1(((g.Nx + 255) / 256) * (g.jm_hi - g.jm_lo + 1));
-    // tuning / cross-check knobs, read per call (tests/test_gpu_variants.py switches them in-process):
-    //   TPG_CELLS_VARIANT 3 = k_cells_tile (default), 2 = k_cells_fast, 1 = k_cells_march, 0 = k_cells (thread per cell)
-    //   TPG_BUILD_NT      1 = streaming stores (default), 0 = plain stores
-    //   TPG_CELLS_STRIP   rows per strip of the marching kernels (default: one resident round)
-    //   TPG_CELLS_CAPACITY fraction of the wave slots that round may assume (default 1)
-    const bool nt = getenv("TPG_BUILD_NT") ? atoi(getenv("TPG_BUILD_NT")) != 0 : true;
-    int variant = getenv("TPG_CELLS_VARIANT") ? atoi(getenv("TPG_CELLS_VARIANT")) : 3;
-    if (variant == 3 && (g.jm_hi - g.jm_lo + 1 + 6) / 7 > 65535) variant = 2;     // tile rows ride on gridDim.y
-    const int strip_rows = getenv("TPG_CELLS_STRIP") ? atoi(getenv("TPG_CELLS_STRIP")) : 0;
-    if (variant == 3) {
-        constexpr int R = 8;                                   // point rows per tile (16 = one block per CU: measured 25 % slower)
-        const int tiles_x = (g.Nx + 61) / 62;
-        const int nrows = g.jm_hi - g.jm_lo + 1;
-        const int tiles_y = (nrows + (R - 1) - 1) / (R - 1);
+    // knobs (tpg::config(), read once): TPG_CELLS_VARIANT 3 = k_cells_tile (default), 0 = k_cells (thread per cell,
+    // the cross-check: tests/test_gpu_variants.py); TPG_BUILD_NT 1 = streaming stores (default), 0 = plain stores
+    const tpg::Config& cfg = tpg::config();
+    const bool nt = cfg.build_nt;
+    constexpr int R = 8;                                       // point rows per tile (16 = one block per CU: measured 25 % slower)
+    const int nrows = g.jm_hi - g.jm_lo + 1;
+    const int tiles_x = (g.Nx + 61) / 62;
+    const int tiles_y = (nrows + (R - 1) - 1) / (R - 1);
+    if (cfg.cells_variant == 3 && tiles_y <= 65535) {          // tile rows ride on gridDim.y
         dim3 gridt((unsigned)tiles_x, (unsigned)tiles_y);
         if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x);
         else    hipLaunchKernelGGL((k_cells_tile<T, false, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x);
-    }
-    else if (variant == 1 || variant == 2) {
-        // strips sized so that the whole grid is (just under) one resident round of waves:
-        // equal work per wave, no tail; short strips cost one extra point row each
-        MarchArgs m;
-        m.nwx = (g.Nx + 61) / 62;
-        const int nrows = g.jm_hi - g.jm_lo + 1;
-        int L = strip_rows;
-        if (L <= 0) {
-            static int resident_waves = 0;
-            if (!resident_waves) {
-                int dev = 0, cus = 256, blocks = 2;
-                (void)hipGetDevice(&dev);
-                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-                if (variant == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_cells_fast<T, true>, 256, 0);
-                else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_cells_march<T, true>, 256, 0);
-                if (blocks < 1) blocks = 1;
-                resident_waves = cus * blocks * 4;
-            }
-            // TPG_CELLS_CAPACITY (0 < f <= 1): fraction of the wave slots to plan for -- below 1 when another
-            // kernel (e.g. RCCL send/recv of an overlapped halo exchange) shares the GPU, so that the
-            // build still fits one resident round instead of spilling a few blocks into a second one
-            double cap = getenv("TPG_CELLS_CAPACITY") ? atof(getenv("TPG_CELLS_CAPACITY")) : 1.0;
-            if (!(cap > 0.05 && cap <= 1.0)) cap = 1.0;
-            int strips = (int)(resident_waves * cap) / m.nwx;
-            if (strips < 1) strips = 1;
-            L = (nrows + strips - 1) / strips;
-            if (L < 8) L = nrows < 8 ? nrows : 8;
-        }
-        m.L = L;
-        const int nstrips = (nrows + L - 1) / L;
-        const int nwaves = nstrips * m.nwx;
-        dim3 gridm((nwaves + 3) / 4);
-        if (variant == 2) {
-            if (nt) hipLaunchKernelGGL((k_cells_fast<T, true>), gridm, dim3(256), 0, s, g, o, m);
-            else    hipLaunchKernelGGL((k_cells_fast<T, false>), gridm, dim3(256), 0, s, g, o, m);
-        } else {
-            if (nt) hipLaunchKernelGGL((k_cells_march<T, true>), gridm, dim3(256), 0, s, g, o, m);
-            else    hipLaunchKernelGGL((k_cells_march<T, false>), gridm, dim3(256), 0, s, g, o, m);
-        }
     }
     else if (nt) hipLaunchKernelGGL((k_cells<T, true>), grid1, dim3(256), 0, s, g, o);
     else         hipLaunchKernelGGL((k_cells<T, false>), grid1, dim3(256), 0, s, g, o);

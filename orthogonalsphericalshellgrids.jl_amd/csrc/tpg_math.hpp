@@ -309,6 +309,28 @@ TPG_DEV double asinD(double x)
     return csign(res, x);
 }
 
+// ---- acos (msun e_acos.c; the same p/q as asin) -- used by the non-orthogonality diagnostic only
+TPG_DEV double acosD(double x)
+{
+    double ax = absD(x);
+    if (ax >= 1.0) {
+        if (ax == 1.0) return x > 0.0 ? 0.0 : kPi;
+        return (x - x) / (x - x);
+    }
+    if (ax < 0.5) {
+        if (ax < 0x1p-54) return kPio2Hi;                          // eps/4: pi/2 to the last bit
+        double z = x * x;
+        return kPio2Hi - (x - (kPio2Lo - x * asin_pq(z)));
+    }
+    double z = (1.0 - ax) * 0.5;
+    double r = asin_pq(z);
+    double s = sqrt(z);
+    if (x < 0.0) return kPi - 2.0 * (s + (r * s - kPio2Lo));
+    double f = from_bits(bits(s) & 0xffffffff00000000ull);
+    double c = (z - f * f) / (s + f);
+    return 2.0 * (f + (r * s + c));
+}
+
 // ---- double-double toolkit (latitude-stretching table only)
 struct dd { double hi, lo; };
 TPG_DEV dd two_sum(double a, double b) { double s = a + b, bb = s - a; return { s, (a - (s - bb)) + (b - bb) }; }

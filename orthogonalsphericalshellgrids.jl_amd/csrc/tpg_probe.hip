@@ -11,7 +11,7 @@ using namespace tpgm;
 
 namespace {
 
-enum { F_SIN, F_COS, F_SIND, F_COSD, F_TAND, F_ATAN, F_ASIN, F_ASINH, F_SINH, F_COSH,          // scalar
+enum { F_SIN, F_COS, F_SIND, F_COSD, F_TAND, F_ATAN, F_ASIN, F_ASINH, F_SINH, F_COSH, F_ACOS,          // scalar
        F_SQRT_NR = 20, F_DIV_NR = 21,                                                          // unscaled sqrt / division
        B_SIN_SMALL = 100, B_COS, B_ATAN, B_ATAN_TAB, B_ATAN_SMALL, B_ASIN_SMALL, B_SIND, B_COSD }; // batch
 
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void k_probe(int which, const double* __restri
     case F_ASINH: y[t] = asinhD(v); break;
     case F_SINH:  sinh_cosh(v, s, c); y[t] = s; break;
     case F_COSH:  sinh_cosh(v, s, c); y[t] = c; break;
+    case F_ACOS:  y[t] = acosD(v); break;
     case F_SQRT_NR: y[t] = sqrt_nr(v); break;
     case F_DIV_NR:  y[t] = div_nr(x[t & ~1ll], x[(t | 1) < n ? (t | 1) : t]); break;   // pairs (a, b): both slots get a / b
     default: y[t] = 0.0;

@@ -19,7 +19,6 @@
 // f32, misaligned base pointers) run the scalar kernel (one element per item).
 #include "tpg_common.hpp"
 #include <hip/hip_ext.h>
-#include <stdlib.h>
 
 namespace {
 
@@ -128,7 +127,11 @@ __global__ __launch_bounds__(256) void k_zipper_vec(FieldTable ft, ZipArgs a)
 // the first store, so a wave keeps (Hy+2) KiB in flight instead of 1 KiB -- the fold moves only
 // ~70 MB per launch, which makes it latency- rather than bandwidth-limited unless every wave
 // carries many outstanding requests.
-template <typename T, int W, int HY, bool NTL, int NTS>
+// Loads are streaming (non-temporal): the fold's sources are not reused soon, and a predecessor that left the
+// caches full of dirty lines costs 17.7 instead of 23.6 us that way; stores are plain (tools/fillbench).
+// COPY = true is the bench's same-shape copy ceiling (tpg_zipper_copy_probe): identical rows, bytes and launch
+// shape, but destination column = source column and no sign.
+template <typename T, int W, int HY, bool COPY>
 __global__ __launch_bounds__(256) void k_zipper_cols(FieldTable ft, ZipArgs a)
 {
     typedef typename Vec<T, W>::aligned_t vec_t;
@@ -150,17 +153,17 @@ __global__ __launch_bounds__(256) void k_zipper_cols(FieldTable ft, ZipArgs a)
     const bool fix = (yl == TPG_CENTER) && (ch >= a.fix0);
     // x-Face, first chunk: element i = 1 wraps to i' = 1 with |sign| (:73-75, :90-92); the mirrored
     // window then starts one element into the east halo, whose (unused) value is replaced below
-    const bool wrap = (xl == TPG_FACE) && (ch == 0);
+    const bool wrap = !COPY && (xl == TPG_FACE) && (ch == 0);
 
     // mirrored source window: x-Center i' = Nx-i+1, x-Face i' = Nx-i+2 (one element to the right)
-    const int soff = a.Nx - i - W + 1 + (xl == TPG_FACE ? 1 : 0);
+    const int soff = COPY ? i - 1 : a.Nx - i - W + 1 + (xl == TPG_FACE ? 1 : 0);
     vec_t v[HY];
     T w0[HY];
 #pragma unroll
     for (int jr = 1; jr <= HY; ++jr) {
         const T* row = lvl + sx * (prow_ny - jr + ysh);
         const lvec_t* p = reinterpret_cast<const lvec_t*>(row + soff);
-        if (NTL) v[jr - 1] = __builtin_nontemporal_load(p); else v[jr - 1] = *p;
+        v[jr - 1] = __builtin_nontemporal_load(p);
         w0[jr - 1] = wrap ? row[0] : (T)0;
     }
     vec_t vf = {}, old = {};
@@ -174,16 +177,15 @@ __global__ __launch_bounds__(256) void k_zipper_cols(FieldTable ft, ZipArgs a)
     for (int jr = 1; jr <= HY; ++jr) {
         vec_t o;
 #pragma unroll
-        for (int e = 0; e < W; ++e) o[e] = s * v[jr - 1][W - 1 - e];
+        for (int e = 0; e < W; ++e) o[e] = COPY ? v[jr - 1][e] : s * v[jr - 1][W - 1 - e];
         if (wrap) o[0] = as * w0[jr - 1];
-        vec_t* q = reinterpret_cast<vec_t*>(lvl + sx * (prow_ny + jr) + (i - 1));
-        if (NTS == 1) __builtin_nontemporal_store(o, q); else *q = o;
+        *reinterpret_cast<vec_t*>(lvl + sx * (prow_ny + jr) + (i - 1)) = o;
     }
     if (fix) {
         // c[i,Ny] = ifelse(i > Nx/2, sign*c[i',Ny], c[i,Ny]) (:102,:135); i = 1 is never > Nx/2
         vec_t o;
 #pragma unroll
-        for (int e = 0; e < W; ++e) o[e] = (i + e > a.Nx / 2) ? s * vf[W - 1 - e] : old[e];
+        for (int e = 0; e < W; ++e) o[e] = (i + e > a.Nx / 2) ? (COPY ? vf[e] : s * vf[W - 1 - e]) : old[e];
         *reinterpret_cast<vec_t*>(lvl + sx * prow_ny + (i - 1)) = o;
     }
 }
@@ -377,47 +379,38 @@ thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
             hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                              \
     } while (0)
 
-template <typename T, int W, bool NTL, int NTS>
+template <typename T, int W, bool COPY>
 void launch_cols(int Hy, dim3 grid, hipStream_t s, const FieldTable& ft, const ZipArgs& a)
 {
     switch (Hy) {
-    case 1: TPG_LAUNCH((k_zipper_cols<T, W, 1, NTL, NTS>), grid, dim3(256), s, ft, a); break;
-    case 2: TPG_LAUNCH((k_zipper_cols<T, W, 2, NTL, NTS>), grid, dim3(256), s, ft, a); break;
-    case 3: TPG_LAUNCH((k_zipper_cols<T, W, 3, NTL, NTS>), grid, dim3(256), s, ft, a); break;
-    case 4: TPG_LAUNCH((k_zipper_cols<T, W, 4, NTL, NTS>), grid, dim3(256), s, ft, a); break;
-    case 5: TPG_LAUNCH((k_zipper_cols<T, W, 5, NTL, NTS>), grid, dim3(256), s, ft, a); break;
-    case 6: TPG_LAUNCH((k_zipper_cols<T, W, 6, NTL, NTS>), grid, dim3(256), s, ft, a); break;
-    case 7: TPG_LAUNCH((k_zipper_cols<T, W, 7, NTL, NTS>), grid, dim3(256), s, ft, a); break;
-    default: TPG_LAUNCH((k_zipper_cols<T, W, 8, NTL, NTS>), grid, dim3(256), s, ft, a); break;
+    case 1: TPG_LAUNCH((k_zipper_cols<T, W, 1, COPY>), grid, dim3(256), s, ft, a); break;
+    case 2: TPG_LAUNCH((k_zipper_cols<T, W, 2, COPY>), grid, dim3(256), s, ft, a); break;
+    case 3: TPG_LAUNCH((k_zipper_cols<T, W, 3, COPY>), grid, dim3(256), s, ft, a); break;
+    case 4: TPG_LAUNCH((k_zipper_cols<T, W, 4, COPY>), grid, dim3(256), s, ft, a); break;
+    case 5: TPG_LAUNCH((k_zipper_cols<T, W, 5, COPY>), grid, dim3(256), s, ft, a); break;
+    case 6: TPG_LAUNCH((k_zipper_cols<T, W, 6, COPY>), grid, dim3(256), s, ft, a); break;
+    case 7: TPG_LAUNCH((k_zipper_cols<T, W, 7, COPY>), grid, dim3(256), s, ft, a); break;
+    default: TPG_LAUNCH((k_zipper_cols<T, W, 8, COPY>), grid, dim3(256), s, ft, a); break;
     }
 }
 
-// TPG_ZIPPER_VARIANT (tools/zipper_tune.sh): 0 row items, 1 columns, 2 columns + nontemporal loads and
-// stores, 3 columns + nontemporal loads (DEFAULT), 4 columns + nontemporal stores.
-// Measured at config 3 (kernel events, us): warm / cold-clean / cold-dirty caches
-//   1: 12.6 / 16.8 / 23.6    3: 14.9 / 16.6 / 17.7
-// and inside bench.py (rocprofv3 avg, after the grid build): 1: 17.6  3: 16.1.
-// The fold's sources are not reused soon, so streaming loads cost nothing in a real step and make the
-// kernel robust against a predecessor that left the caches dirty.  Write-through (sc1 / sc0 sc1) stores
-// were tried through inline asm: they remove the end-of-kernel L2 write-back when the lines are cache
-// resident (78 % of 8 TB/s) but do not help the cold case, which is bounded by first-byte latency -- and
-// an inline-asm 128-bit store escapes the compiler's hazard recogniser (the next VALU write of its data
-// registers corrupted Float32 folds; found by tools/soak_fill.py), so those forms were removed.
-// 512/1024-thread blocks, two levels per thread and occupancy throttling were measured too: 3-15 % slower.
-int zipper_variant()
-{
-    const char* e = getenv("TPG_ZIPPER_VARIANT");
-    return e ? atoi(e) : 3;
-}
-
-template <typename T, int W>
+// Kernel choice: column items (k_zipper_cols) wherever rows are 16-B chunkable and Hy <= 8; row items otherwise
+// (k_zipper_vec for Hy > 8 -- e.g. the extended north halo of the split-explicit free surface --, k_zipper_scalar for
+// odd Hx / misaligned pointers).  TPG_ZIPPER_VARIANT=0 forces the row kernels everywhere (cross-check,
+// tests/test_gpu_variants.py).  What was measured and dropped (tools/fillbench, profiles/r02/fillbench_ab.txt):
+// plain loads (cold-dirty 26 vs 20 us), non-temporal stores (+2 us), write-through sc1 / sc0 sc1 buffer stores
+// (-0.5 us cold-clean, +0 dirty), a persistent software-pipelined grid (1024 blocks, loads of item n+1 ahead of the
+// stores of item n: -0.5 us), two half-row chunks per thread (one resident round of 4224 waves: +-0), 512 / 1024-thread
+// blocks, two levels per thread (slower).  All of them, and same-shape pure copies, sit at 14.7-16.1 us cold:
+// the 73 MB launch is at the copy ceiling of this access shape.
+template <typename T, int W, bool COPY = false>
 int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                  const Geom& g, int kstart, int kcount, hipStream_t s)
 {
     bool vec = (g.Hx % W == 0) && (g.Nx % W == 0);
     for (int f = 0; f < n && vec; ++f) vec = ((uintptr_t)fields[f] % 16) == 0;
-    const int variant = zipper_variant();
-    const bool cols = vec && g.Hy >= 1 && g.Hy <= 8 && variant != 0;    // Hy = 0: only the row-Ny substitution remains (row kernels)
+    const bool cols = vec && g.Hy >= 1 && g.Hy <= 8 && (COPY || tpg::config().zipper_variant != 0);    // Hy = 0: only the row-Ny substitution remains (row kernels)
+    if (COPY && !cols) { tpg::set_error("copy probe: geometry has no column kernel"); return TPG_ERR_UNSUPPORTED; }
 
     FieldTable ft;
     ZipArgs a;
@@ -440,10 +433,7 @@ int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t 
     dim3 grid((unsigned)((total + 255) / 256));
     if (cols) {
         dim3 grid2((unsigned)(((long long)kcount * a.nchunks + 255) / 256), (unsigned)n);
-        if (variant == 2)      launch_cols<T, W, true, 1>(g.Hy, grid2, s, ft, a);
-        else if (variant == 3) launch_cols<T, W, true, 0>(g.Hy, grid2, s, ft, a);
-        else if (variant == 4) launch_cols<T, W, false, 1>(g.Hy, grid2, s, ft, a);
-        else                   launch_cols<T, W, false, 0>(g.Hy, grid2, s, ft, a);
+        launch_cols<T, W, COPY>(g.Hy, grid2, s, ft, a);
     }
     else if (vec) TPG_LAUNCH((k_zipper_vec<T, W>), grid, dim3(256), s, ft, a);
     else          TPG_LAUNCH((k_zipper_scalar<T>), grid, dim3(256), s, ft, a);
@@ -494,6 +484,26 @@ int tpg_zipper_fill_timed(void* const fields[], int nfields, const int8_t xloc[]
     g_ev_start = static_cast<hipEvent_t>(start_event);
     g_ev_stop = static_cast<hipEvent_t>(stop_event);
     int rc = tpg_zipper_fill(fields, nfields, xloc, yloc, sign, Nx, Ny, Nz, Hx, Hy, Hz, kstart, kcount, ft, stream);
+    g_ev_start = g_ev_stop = nullptr;
+    return rc;
+}
+
+int tpg_zipper_copy_probe(void* const fields[], int nfields, const int8_t yloc[],
+                          int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream,
+                          void* start_event, void* stop_event)
+{
+    int rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft);
+    if (rc) return rc;
+    if ((rc = check_fields(fields, nfields))) return rc;
+    if (!yloc) { tpg::set_error("null location table"); return TPG_ERR_INVALID_ARGUMENT; }
+    if (nfields > TPG_MAX_FIELDS) { tpg::set_error("copy probe: at most %d fields (one kernel)", TPG_MAX_FIELDS); return TPG_ERR_UNSUPPORTED; }
+    int8_t xl[TPG_MAX_FIELDS]; int32_t sg[TPG_MAX_FIELDS];
+    for (int f = 0; f < nfields; ++f) { xl[f] = TPG_CENTER; sg[f] = 1; }
+    Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
+    g_ev_start = static_cast<hipEvent_t>(start_event);
+    g_ev_stop = static_cast<hipEvent_t>(stop_event);
+    rc = (ft == TPG_F64) ? zipper_batch<double, 2, true>(fields, nfields, xl, yloc, sg, g, 1, Nz, tpg::as_stream(stream))
+                         : zipper_batch<float, 4, true>(fields, nfields, xl, yloc, sg, g, 1, Nz, tpg::as_stream(stream));
     g_ev_start = g_ev_stop = nullptr;
     return rc;
 }
@@ -559,8 +569,7 @@ int tpg_fill_halo_regions(void* const fields[], int nfields, const int8_t xloc[]
 {
     int rc = TPG_OK;
     // small fields: one fused launch (k_fill_fused); TPG_FILL_FUSED=0 never, =1 whenever the geometry allows
-    const char* knob = getenv("TPG_FILL_FUSED");
-    const int mode = knob ? atoi(knob) : -1;
+    const int mode = tpg::config().fill_fused;
     if (north_is_zipper && mode != 0 && Hx > 0 && Hy > 0 && Nx >= 2 * Hx + 2 && Ny >= 2 * Hy + 2) {
         const long long per_level = (long long)(Hy + 1) * (Nx + 2 * Hx) + 2ll * Hx * (Ny + Hy - 1);
         const long long items = per_level * (Nz + 2 * Hz);

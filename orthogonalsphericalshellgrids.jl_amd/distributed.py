@@ -4,10 +4,19 @@ Reference: the reference forbids x-partitioning (src/distributed_tripolar_grid.j
 the seam traffic to Oceananigans' DistributedComputations (MPI Isend/Irecv of one packed buffer per
 side; reached from :171,195).  Here: one process per GPU; each interior seam swaps Hy full rows
 (all i incl. x halos, all levels incl. z halos) in both directions with point-to-point RCCL
-send/recv over xGMI (torch.distributed backend "nccl"); gathering / scattering between the padded
-fields and the contiguous message is done by the HIP kernels tpg_pack_y_halo / tpg_unpack_y_halo.
-No collective is involved: a y-slab chain only ever talks to its two neighbours.
+send/recv over xGMI.  No collective is involved: a y-slab chain only ever talks to its two neighbours.
+
+Three transports, all bit-identical in what they deliver:
+  * RcclComm (the production path): the C ABI's tpg_halo_exchange_y -- pack -> ONE ncclGroupStart/End of
+    ncclSend/ncclRecv on the caller's stream -> unpack (or pack-free: the per-level contiguous seam windows sent
+    from / received into the fields directly).  No host wait, capturable in a HIP graph.  The communicator is
+    librccl's own (tpg_comm_init_rank); torch.distributed only ferries the 128-byte unique id.
+  * torch_distributed_transport: `batch_isend_irecv` of the packed messages (backend "nccl" = RCCL, or "gloo" with
+    host tensors): the Python convenience, and what the CPU/gloo tests of the host protocol run.
+  * any object with post(plan, send, recv, group) / wait(handle) (two-phase), or a plain callable
+    transport(plan, send, recv, group): test transports (loop-back emulation of R ranks on one GPU, host staging).
 """
+import ctypes as C
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional
 
@@ -38,18 +47,97 @@ def exchange_plan(rank: int, nranks: int) -> List[SeamMessage]:
     return plan
 
 
-def torch_distributed_transport(plan, send: Dict[int, torch.Tensor], recv: Dict[int, torch.Tensor], group=None):
+# -------------------------------------------------------------------------------------------------
+# transports
+# -------------------------------------------------------------------------------------------------
+class TorchDistributedTransport:
     """All sends/recvs of one halo fill as ONE batched point-to-point group
     (ncclGroupStart/End under the "nccl" = RCCL backend; also valid on "gloo")."""
-    import torch.distributed as dist
-    if not plan:
-        return
-    ops = []
-    for m in plan:
-        ops.append(dist.P2POp(dist.isend, send[m.side], m.peer, group))
-        ops.append(dist.P2POp(dist.irecv, recv[m.side], m.peer, group))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
+
+    def post(self, plan, send: Dict[int, torch.Tensor], recv: Dict[int, torch.Tensor], group=None):
+        import torch.distributed as dist
+        if not plan:
+            return []
+        ops = []
+        for m in plan:
+            ops.append(dist.P2POp(dist.isend, send[m.side], m.peer, group))
+            ops.append(dist.P2POp(dist.irecv, recv[m.side], m.peer, group))
+        return dist.batch_isend_irecv(ops)
+
+    def wait(self, handle):
+        # "nccl": makes the current stream wait for the communication (no host block); "gloo": blocks the host
+        for req in handle:
+            req.wait()
+
+    def __call__(self, plan, send, recv, group=None):
+        self.wait(self.post(plan, send, recv, group))
+
+
+torch_distributed_transport = TorchDistributedTransport()
+
+
+class LoopbackMailbox:
+    """Two-phase transport for R latitude-band ranks emulated in ONE process on one GPU (tests/test_gpu_distributed.py,
+    tools/soak_distributed.py): post() parks the rank's packed messages in a shared mailbox, wait() delivers the peers'
+    messages into the receive buffers.  Drive it as: plan_r.begin() for every rank r, then plan_r.finish() for every r."""
+
+    def __init__(self):
+        self.box = {}
+
+    def endpoint(self, me):
+        return _LoopbackEndpoint(self.box, me)
+
+
+class _LoopbackEndpoint:
+    def __init__(self, box, me):
+        self.box, self.me = box, me
+
+    def post(self, plan, send, recv, group=None):
+        for m in plan:
+            self.box.setdefault((self.me, m.peer), []).append(send[m.side].clone())
+        return plan, recv
+
+    def wait(self, handle):
+        plan, recv = handle
+        for m in plan:
+            recv[m.side].copy_(self.box[(m.peer, self.me)].pop(0))
+
+
+class RcclComm:
+    """ncclComm_t of the latitude-band chain, created through the C ABI (tpg_comm_init_rank: librccl's
+    ncclCommInitRank on the current device).  `RcclComm.from_torch(group)` bootstraps it over an initialised
+    torch.distributed group of any backend: rank 0 draws the unique id, broadcast_object_list ferries it."""
+
+    def __init__(self, handle, rank, nranks):
+        self.handle, self.rank, self.nranks = handle, rank, nranks
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * _lib.TPG_COMM_ID_BYTES)()
+        _lib.check(_lib.lib().tpg_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf.raw)
+
+    @classmethod
+    def create(cls, unique_id: bytes, rank: int, nranks: int):
+        if len(unique_id) != _lib.TPG_COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        comm = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, _lib.TPG_COMM_ID_BYTES)
+        _lib.check(_lib.lib().tpg_comm_init_rank(C.byref(comm), nranks, C.cast(buf, C.c_void_p), rank))
+        return cls(comm, rank, nranks)
+
+    @classmethod
+    def from_torch(cls, group=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls.create(box[0], rank, world)
+
+    def destroy(self):
+        if self.handle is not None:
+            _lib.check(_lib.lib().tpg_comm_destroy(self.handle))
+            self.handle = None
 
 
 def message_shape(nfields, f):
@@ -72,26 +160,71 @@ def _message_buffers(shape, dtype, device, plan):
     return bufs["send"], bufs["recv"]
 
 
-def exchange_y_halos(fields, arch, transport: Optional[Callable] = None):
-    """Fill the y-seam halo rows of `fields` (one geometry) from the neighbour ranks."""
-    plan = exchange_plan(arch.local_rank, arch.ranks[1])
-    if not plan:
-        return
-    transport = transport or torch_distributed_transport
-    lib = _lib.lib()
-    f0 = fields[0]
-    geom = (f0.Nx, f0.Ny, f0.Nz, f0.Hx, f0.Hy, f0.Hz)
-    ft = _lib.ft_of(f0.data.dtype)
-    dev = f0.data.device
-    for b0 in range(0, len(fields), _lib.TPG_MAX_FIELDS):
-        batch = fields[b0:b0 + _lib.TPG_MAX_FIELDS]
-        ptrs = _lib.ptr_table([f.data for f in batch])
-        shape = message_shape(len(batch), f0)
-        send, recv = _message_buffers(shape, f0.data.dtype, dev, plan)
+class PendingExchange:
+    """A posted seam exchange: begin = pack + post, finish = wait + unpack.  Splitting the two lets a single
+    process drive several emulated ranks (all post, then all finish) and lets a caller put work between them."""
+
+    def __init__(self, fields, arch, transport=None, pack_free=False):
+        self.plan = exchange_plan(arch.local_rank, arch.ranks[1])
+        self.fields, self.arch = list(fields), arch
+        self.comm = getattr(arch, "rccl_comm", None) if transport is None else None
+        self.transport = transport if transport is not None else torch_distributed_transport
+        self.pack_free = pack_free
+        self._batches = []
+
+    def begin(self):
+        if not self.plan:
+            return self
+        lib = _lib.lib()
+        f0 = self.fields[0]
+        geom = (f0.Nx, f0.Ny, f0.Nz, f0.Hx, f0.Hy, f0.Hz)
+        ft = _lib.ft_of(f0.data.dtype)
+        dev = f0.data.device
+        for b0 in range(0, len(self.fields), _lib.TPG_MAX_FIELDS):
+            batch = self.fields[b0:b0 + _lib.TPG_MAX_FIELDS]
+            ptrs = _lib.ptr_table([f.data for f in batch])
+            if self.comm is not None and self.pack_free:
+                self._batches.append((batch, ptrs, None, None, None))
+                continue
+            send, recv = _message_buffers(message_shape(len(batch), f0), f0.data.dtype, dev, self.plan)
+            handle = None
+            if self.comm is None:
+                with torch.cuda.device(dev):
+                    stream = _lib.current_stream_ptr(dev)
+                    for m in self.plan:
+                        _lib.check(lib.tpg_pack_y_halo(ptrs, len(batch), send[m.side].data_ptr(), m.side, *geom, ft, stream))
+                    if hasattr(self.transport, "post"):
+                        handle = self.transport.post(self.plan, send, recv, getattr(self.arch, "process_group", None))
+            self._batches.append((batch, ptrs, send, recv, handle))
+        return self
+
+    def finish(self):
+        if not self.plan:
+            return
+        lib = _lib.lib()
+        f0 = self.fields[0]
+        geom = (f0.Nx, f0.Ny, f0.Nz, f0.Hx, f0.Hy, f0.Hz)
+        ft = _lib.ft_of(f0.data.dtype)
+        dev = f0.data.device
         with torch.cuda.device(dev):
             stream = _lib.current_stream_ptr(dev)
-            for m in plan:
-                _lib.check(lib.tpg_pack_y_halo(ptrs, len(batch), send[m.side].data_ptr(), m.side, *geom, ft, stream))
-            transport(plan, send, recv, getattr(arch, "process_group", None))
-            for m in plan:
-                _lib.check(lib.tpg_unpack_y_halo(ptrs, len(batch), recv[m.side].data_ptr(), m.side, *geom, ft, stream))
+            for batch, ptrs, send, recv, handle in self._batches:
+                if self.comm is not None:
+                    # the C ABI's exchange: pack -> one RCCL send/recv group -> unpack, all on `stream`, no host wait
+                    p = lambda d, side: None if d is None or side not in d else d[side].data_ptr()
+                    _lib.check(lib.tpg_halo_exchange_y(self.comm.handle, self.arch.local_rank, self.arch.ranks[1], ptrs, len(batch),
+                                                       p(send, SOUTH), p(send, NORTH), p(recv, SOUTH), p(recv, NORTH), *geom, ft, stream))
+                    continue
+                group = getattr(self.arch, "process_group", None)
+                if hasattr(self.transport, "post"):
+                    self.transport.wait(handle)
+                else:
+                    self.transport(self.plan, send, recv, group)
+                for m in self.plan:
+                    _lib.check(lib.tpg_unpack_y_halo(ptrs, len(batch), recv[m.side].data_ptr(), m.side, *geom, ft, stream))
+        self._batches = []
+
+
+def exchange_y_halos(fields, arch, transport: Optional[Callable] = None, pack_free: bool = False):
+    """Fill the y-seam halo rows of `fields` (one geometry) from the neighbour ranks."""
+    PendingExchange(fields, arch, transport, pack_free).begin().finish()

@@ -151,6 +151,28 @@ def _groups(fields):
     return groups.values()
 
 
+def _check_supported(f):
+    """Scope of this halo fill: the north Zipper (the reference's own code), Oceananigans' periodic x pass
+    that must follow it, and the latitude-band seams.  South / bottom / top conditions and non-periodic x conditions are
+    Oceananigans' (the reference's own fills leave them `nothing`, src/tripolar_grid.jl:147-152): a field that carries one
+    is refused loudly instead of being returned with stale halos."""
+    from .boundary_conditions import HaloCommunication, Periodic
+    bcs = f.boundary_conditions
+    for side in ("west", "east"):
+        bc = getattr(bcs, side)
+        if bc is not None and not isinstance(bc.classification, Periodic):
+            raise NotImplementedError(f"fill_halo_regions: {side} boundary condition {bc.classification!r} is not handled "
+                                      "(tripolar grids are Periodic in x)")
+    for side in ("south", "north"):
+        bc = getattr(bcs, side)
+        if bc is not None and not is_zipper(bc) and not isinstance(bc.classification, HaloCommunication):
+            raise NotImplementedError(f"fill_halo_regions: {side} boundary condition {bc.classification!r} is Oceananigans' to fill; "
+                                      "this library fills the Zipper north side, periodic x and the latitude-band seams only")
+    for side in ("bottom", "top"):
+        if getattr(bcs, side) is not None:
+            raise NotImplementedError(f"fill_halo_regions: {side} boundary conditions (z halos) are Oceananigans' to fill, not handled here")
+
+
 def _tables(fs):
     xl, yl, sg = [], [], []
     for f in fs:
@@ -178,13 +200,18 @@ class HaloFillPlan:
     The plan holds the fields' tensors: it must be rebuilt if a field's `data` is replaced.
     """
 
-    def __init__(self, fields, *, exchange=None):
+    def __init__(self, fields, *, exchange=None, pack_free=False):
         if isinstance(fields, Field):
             fields = [fields]
         self.fields = list(fields)
         self._exchange = exchange
+        self._pack_free = pack_free
+        self._pending = []
         self._steps = []                      # (device, [(c function, argument tuple without the stream)], seam fields, arch)
         lib = _lib.lib()
+        for f in self.fields:
+            if f.boundary_conditions is not None:
+                _check_supported(f)
         for fs in _groups(self.fields):
             f0 = fs[0]
             g = getattr(f0.grid, "underlying_grid", f0.grid)
@@ -207,7 +234,9 @@ class HaloFillPlan:
             seam = fs if getattr(arch, "is_distributed", False) and arch.ranks[1] > 1 else None
             self._steps.append((f0.data.device, calls, seam, arch))
 
-    def __call__(self):
+    def begin(self):
+        """local part of the fill (zipper, periodic x) on every geometry group, then pack + post of the seam exchange"""
+        self._pending = []
         for device, calls, seam, arch in self._steps:
             if torch.cuda.current_device() == device.index:     # the common case: no device switch to pay for
                 stream = _lib.current_stream_ptr(device)
@@ -219,18 +248,30 @@ class HaloFillPlan:
                     for fn, args in calls:
                         _lib.check(fn(*args, stream))
             if seam is not None:
-                from .distributed import exchange_y_halos
-                exchange_y_halos(seam, arch, transport=self._exchange)
+                from .distributed import PendingExchange
+                self._pending.append(PendingExchange(seam, arch, self._exchange, self._pack_free).begin())
+        return self
+
+    def finish(self):
+        """delivery + unpack of the seam messages posted by begin()"""
+        for p in self._pending:
+            p.finish()
+        self._pending = []
         return None
 
+    def __call__(self):
+        self.begin()
+        return self.finish()
 
     def graph(self, repeat=1):
         """Capture `repeat` consecutive runs of this plan into one HIP graph (torch.cuda.CUDAGraph) and return
         it; `graph.replay()` then issues the whole sequence with a single launch -- the fills of a
         split-explicit sub-cycle are launch-bound, 2.7 us instead of 7 us per fill.
-        Serial grids only: a seam exchange (torch.distributed) cannot be captured."""
-        if any(seam is not None for _, _, seam, _ in self._steps):
-            raise ValueError("HaloFillPlan.graph: plans with a distributed seam exchange cannot be captured")
+        Distributed plans are capturable only on the C ABI's RCCL exchange (arch.rccl_comm: ncclSend/ncclRecv enqueue on
+        the captured stream); a torch.distributed or test transport cannot be captured."""
+        if any(seam is not None and (self._exchange is not None or getattr(arch, "rccl_comm", None) is None)
+               for _, _, seam, arch in self._steps):
+            raise ValueError("HaloFillPlan.graph: a seam exchange is capturable only through arch.rccl_comm (tpg_halo_exchange_y)")
         self()                                           # first-call work (occupancy queries, lazy module load) outside the capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -243,8 +284,8 @@ class HaloFillPlan:
         return g
 
 
-def halo_fill_plan(fields, *, exchange=None):
-    return HaloFillPlan(fields, exchange=exchange)
+def halo_fill_plan(fields, *, exchange=None, pack_free=False):
+    return HaloFillPlan(fields, exchange=exchange, pack_free=pack_free)
 
 
 def fill_halo_regions(fields, *, exchange=None):

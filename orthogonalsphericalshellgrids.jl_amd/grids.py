@@ -65,9 +65,10 @@ class Distributed:
     is_distributed = True
 
     def __init__(self, child_architecture=None, partition: Optional[Partition] = None,
-                 local_rank: Optional[int] = None, process_group=None):
+                 local_rank: Optional[int] = None, process_group=None, rccl_comm=None):
         self.child_architecture = child_architecture if child_architecture is not None else GPU()
         self.process_group = process_group
+        self.rccl_comm = rccl_comm          # distributed.RcclComm: seam exchanges go through tpg_halo_exchange_y (C ABI)
         if partition is None:
             import torch.distributed as dist
             partition = Partition(y=dist.get_world_size(process_group) if dist.is_initialized() else 1)

@@ -28,7 +28,7 @@ def test_header_symbols_are_all_exported_and_bound(osg):
 
 def test_version_and_status_strings(osg):
     lib = osg._lib.lib()
-    assert lib.tpg_version() == 100
+    assert lib.tpg_version() == 200
     assert b"even" in lib.tpg_status_string(-2)
     assert lib.tpg_status_string(0) == b"ok"
 

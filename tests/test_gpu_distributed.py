@@ -14,7 +14,6 @@ SPECS = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]
 @pytest.mark.parametrize("R", [2, 4])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype):
-    from orthogonalsphericalshellgrids.jl_amd import fields as F
     size, halo = (48, 40, 3), (4, 4, 2)
     (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
     tdt = torch.float64 if dtype == np.float64 else torch.float32
@@ -43,31 +42,15 @@ def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype):
             fs.append(f)
         ranks.append((arch, grid, fs))
 
-    # phase 1 on every rank: zipper (north rank) + periodic x + pack; messages parked in a mailbox
-    mailbox = {}
-
-    def make_transport(me):
-        def transport(plan, send, recv, group):
-            for m in plan:
-                mailbox[(me, m.peer)] = send[m.side].clone()
-            pending.append((me, plan, recv))
-        return transport
-
-    pending = []
-    lib = osg._lib.lib()
-    for r, (arch, grid, fs) in enumerate(ranks):
-        # run the product's fill up to the transport; unpack happens after all ranks have "sent"
-        F.fill_halo_regions(fs, exchange=make_transport(r))
-    # the unpack inside fill_halo_regions ran on not-yet-delivered buffers; deliver and unpack again
-    for me, plan, recv in pending:
-        arch, grid, fs = ranks[me]
-        f0 = fs[0]
-        for m in plan:
-            recv[m.side].copy_(mailbox[(m.peer, me)])
-            rc = lib.tpg_unpack_y_halo(osg._lib.ptr_table([f.data for f in fs]), len(fs), recv[m.side].data_ptr(), m.side,
-                                       f0.Nx, f0.Ny, f0.Nz, f0.Hx, f0.Hy, f0.Hz, osg._lib.ft_of(f0.data.dtype), None)
-            assert rc == 0
+    # phase 1 on every rank: zipper (north rank) + periodic x + pack + post; phase 2: delivery + the product's own unpack
+    mailbox = osg.LoopbackMailbox()
+    plans = [osg.halo_fill_plan(fs, exchange=mailbox.endpoint(r)) for r, (arch, grid, fs) in enumerate(ranks)]
+    for plan in plans:
+        plan.begin()
+    for plan in plans:
+        plan.finish()
     torch.cuda.synchronize()
+    assert all(not q for q in mailbox.box.values())                                # every posted message was delivered
 
     for (xl, yl, sg), g in zip(SPECS, globs):
         oracle.fill_halo_regions(g, xl, yl, sg, size, halo)

@@ -1,0 +1,39 @@
+"""The C ABI's RCCL seam exchange on hardware.  A 1-GPU box cannot host two RCCL ranks (RCCL refuses two ranks on one
+device), so the data path -- tpg_comm_init_rank, pack -> ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd -> unpack, and
+the pack-free form sending the per-level seam windows directly -- runs on a communicator of ONE rank whose south and north
+peers are the rank itself (tools/rccl_selftest.py), in a child process with a timeout (a mis-paired group would hang).
+Two-rank protocol coverage: tests/test_distributed_gloo.py (world 2, 3 on CPU), tests/test_gpu_distributed.py (emulated
+ranks, real kernels), tests/test_gpu_bench_contract.py::test_bench_two_ranks_rehearsal."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_seam_exchange_single_rank_loopback(gpu):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_selftest.py")], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["single_rank_chain_rc"] == 0
+    assert len(d["cases"]) == 6 and all(c["bit_exact"] for c in d["cases"])
+    assert {c["packed"] for c in d["cases"]} == {True, False}
+
+
+def test_exchange_argument_errors(osg, gpu):
+    import ctypes as C
+    import torch
+    lib = osg._lib.lib()
+    d = torch.zeros((1, 12, 12), dtype=torch.float64, device=gpu)
+    ptr = osg._lib.ptr_table([d])
+    assert lib.tpg_halo_exchange_y(None, 0, 2, ptr, 1, None, None, None, None, 4, 4, 1, 4, 4, 0, 1, None) == -1      # null communicator
+    assert lib.tpg_halo_exchange_y(1 << 20, 2, 2, ptr, 1, None, None, None, None, 4, 4, 1, 4, 4, 0, 1, None) == -3   # rank outside the chain
+    buf = torch.zeros(4 * 12, dtype=torch.float64, device=gpu)
+    # packed exchange with a peer on the north side but no north buffers: refused before any RCCL call
+    assert lib.tpg_halo_exchange_y(1 << 20, 0, 2, ptr, 1, buf.data_ptr(), None, buf.data_ptr(), None, 4, 4, 1, 4, 4, 0, 1, None) == -1
+    assert b"message buffer" in lib.tpg_last_error()

@@ -1,6 +1,6 @@
-"""Every kernel variant kept in the library (the simple thread-per-cell build kernel, the two marching
-kernels, the LDS-tile default; the zipper's row / column / streaming forms) must produce identical bits: they differ only in how the same arithmetic is
-scheduled.  The TPG_* knobs are read per call."""
+"""Every kernel variant kept in the library (the simple thread-per-cell build kernel and the LDS-tile default; the
+zipper's row-item and column-item forms) must produce identical bits: they differ only in how the same arithmetic is
+scheduled.  The TPG_* knobs are read once into an immutable record; tpg_reload_config() publishes a new one."""
 import os
 
 import numpy as np
@@ -8,11 +8,11 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-KNOBS = ("TPG_CELLS_VARIANT", "TPG_BUILD_NT", "TPG_CELLS_STRIP", "TPG_ZIPPER_VARIANT")
+KNOBS = ("TPG_CELLS_VARIANT", "TPG_BUILD_NT", "TPG_ZIPPER_VARIANT")
 
 
 @pytest.fixture
-def knob():
+def knob(osg):
     saved = {k: os.environ.get(k) for k in KNOBS}
     yield os.environ
     for k, v in saved.items():
@@ -20,6 +20,7 @@ def knob():
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
+    osg._lib.lib().tpg_reload_config()
 
 
 @pytest.mark.parametrize("kw", [dict(size=(250, 100, 1)),
@@ -29,11 +30,12 @@ def test_build_kernel_variants_agree(osg, gpu, knob, kw):
     kw = dict(kw)
     dtype = kw.pop("dtype", torch.float64)
     results = {}
-    for variant, nt, strip in ((2, 1, 0), (1, 1, 0), (0, 1, 0), (3, 1, 0), (3, 0, 0), (2, 0, 0), (2, 1, 7), (1, 1, 5)):
-        knob["TPG_CELLS_VARIANT"], knob["TPG_BUILD_NT"], knob["TPG_CELLS_STRIP"] = str(variant), str(nt), str(strip)
+    for variant, nt in ((0, 1), (3, 1), (3, 0), (0, 0)):
+        knob["TPG_CELLS_VARIANT"], knob["TPG_BUILD_NT"] = str(variant), str(nt)
+        osg._lib.lib().tpg_reload_config()
         g = osg.TripolarGrid(osg.GPU(0), dtype, **kw)
-        results[(variant, nt, strip)] = {n: getattr(g, n).cpu().numpy() for n in osg._lib.ARRAY_NAMES}
-    ref = results[(0, 1, 0)]
+        results[(variant, nt)] = {n: getattr(g, n).cpu().numpy() for n in osg._lib.ARRAY_NAMES}
+    ref = results[(0, 1)]
     for key, arrs in results.items():
         for n, a in arrs.items():
             assert np.array_equal(a, ref[n], equal_nan=True), (key, n)
@@ -47,8 +49,9 @@ def test_zipper_kernel_variants_agree(osg, gpu, knob, dtype):
     specs = [(xl, yl, sg) for xl in (0, 1) for yl in (0, 1) for sg in (1, -1)]
     hosts = [rng.uniform(-1, 1, (4 + 4, 40 + 8, 256 + 8)).astype(np.float64 if dtype == torch.float64 else np.float32) for _ in specs]
     outs = {}
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 3):
         knob["TPG_ZIPPER_VARIANT"] = str(variant)
+        osg._lib.lib().tpg_reload_config()
         fs = []
         for (xl, yl, sg), h in zip(specs, hosts):
             loc = (osg.Face if xl else osg.Center, osg.Face if yl else osg.Center, osg.Center)
@@ -60,3 +63,16 @@ def test_zipper_kernel_variants_agree(osg, gpu, knob, dtype):
     for variant, arrs in outs.items():
         for a, b in zip(arrs, outs[0]):
             assert np.array_equal(a, b), variant
+
+
+def test_knobs_are_read_once(osg, gpu, knob):
+    """an environment change without tpg_reload_config() must not flip kernels between calls (getenv per call)"""
+    lib = osg._lib.lib()
+    knob["TPG_ZIPPER_VARIANT"] = "3"
+    lib.tpg_reload_config()
+    knob["TPG_ZIPPER_VARIANT"] = "0"                  # not reloaded: still the column kernel ...
+    d = torch.zeros((1 + 2, 8 + 8, 16 + 8), dtype=torch.float64, device=gpu)
+    import ctypes as C
+    # ... which the copy probe requires (it refuses geometries without a column kernel, not the knob)
+    assert lib.tpg_zipper_copy_probe(osg._lib.ptr_table([d]), 1, (C.c_int8 * 1)(0), 16, 8, 1, 4, 4, 1, 1, None, None, None) == 0
+    torch.cuda.synchronize()

@@ -74,14 +74,30 @@ GEOMS = [((10, 10, 1), (4, 4, 4)), ((60, 30, 3), (4, 4, 4)), ((62, 31, 2), (3, 2
          ((3600, 24, 2), (4, 4, 4))]     # full 1/10 degree rows
 
 
+class _Knob:
+    """TPG_FILL_FUSED through the environment + tpg_reload_config() (the library reads its knobs once)"""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __setitem__(self, k, v):
+        os.environ[k] = v
+        self.lib.tpg_reload_config()
+
+    def pop(self, k, *a):
+        os.environ.pop(k, None)
+        self.lib.tpg_reload_config()
+
+
 @pytest.fixture
-def fused_knob():
+def fused_knob(osg):
     saved = os.environ.get("TPG_FILL_FUSED")
-    yield os.environ
+    yield _Knob(osg._lib.lib())
     if saved is None:
         os.environ.pop("TPG_FILL_FUSED", None)
     else:
         os.environ["TPG_FILL_FUSED"] = saved
+    osg._lib.lib().tpg_reload_config()
 
 
 @pytest.mark.parametrize("fused", ["0", "1"], ids=["two-launch", "fused"])
@@ -116,6 +132,20 @@ def test_mixed_geometries_in_one_call(osg, oracle, gpu):
         sz = (size[0], size[1], f.Nz); hl = (halo[0], halo[1], f.Hz)
         oracle.fill_halo_regions(h, xl, yl, sg, sz, hl)
         assert np.array_equal(f.data.cpu().numpy(), h), f.loc
+
+
+def test_unhandled_boundary_conditions_are_refused(osg, gpu):
+    """south / bottom / top conditions are Oceananigans' to fill: a field carrying one is refused, not returned stale"""
+    grid = osg.TripolarGrid(size=(10, 10, 1))
+    value = osg.BoundaryCondition(object(), 0.0)
+    per = osg.PeriodicBoundaryCondition
+    for side in ("south", "bottom", "top"):
+        c = osg.CenterField(grid, boundary_conditions=osg.FieldBoundaryConditions(west=per(), east=per(), **{side: value}))
+        with pytest.raises(NotImplementedError):
+            osg.fill_halo_regions(c)
+    c = osg.CenterField(grid, boundary_conditions=osg.FieldBoundaryConditions(west=value, east=per()))
+    with pytest.raises(NotImplementedError):
+        osg.fill_halo_regions(c)
 
 
 def test_zipper_only_and_level_range(osg, oracle, gpu):

@@ -5,7 +5,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import orthogonalsphericalshellgrids.jl_amd as osg
-from orthogonalsphericalshellgrids.jl_amd import fields as F
 from oracle import oracle
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -41,20 +40,10 @@ for t in range(trials):
             slab[:, :Hy] = SENT; slab[:, Hy + (jend - jstart + 1):] = SENT
             f.data.copy_(torch.from_numpy(slab)); fs.append(f)
         ranks.append((arch, grid, fs))
-    mailbox, pending = {}, []
-    def make_transport(me):
-        def transport(plan, send, recv, group):
-            for m in plan: mailbox[(me, m.peer)] = send[m.side].clone()
-            pending.append((me, plan, recv))
-        return transport
-    for r, (arch, grid, fs) in enumerate(ranks):
-        F.fill_halo_regions(fs, exchange=make_transport(r))
-    for me, plan, recv in pending:
-        arch, grid, fs = ranks[me]; f0 = fs[0]
-        for m in plan:
-            recv[m.side].copy_(mailbox[(m.peer, me)])
-            assert lib.tpg_unpack_y_halo(osg._lib.ptr_table([f.data for f in fs]), len(fs), recv[m.side].data_ptr(), m.side,
-                                         f0.Nx, f0.Ny, f0.Nz, f0.Hx, f0.Hy, f0.Hz, osg._lib.ft_of(f0.data.dtype), None) == 0
+    mailbox = osg.LoopbackMailbox()
+    plans = [osg.halo_fill_plan(fs, exchange=mailbox.endpoint(r)) for r, (arch, grid, fs) in enumerate(ranks)]
+    for plan in plans: plan.begin()
+    for plan in plans: plan.finish()
     torch.cuda.synchronize()
     for (xl, yl), g in zip(specs, globs):
         oracle.fill_halo_regions(g, xl, yl, -1 if xl != yl else 1, size, halo)      # default sign by location

@@ -17,10 +17,11 @@ for t in range(trials):
     Hx = int(rng.integers(0, min(Nx, 7) + 1)); Hy = int(rng.integers(0, min(Ny, 10) + 1)); Hz = int(rng.integers(0, 3))
     nf = int(rng.integers(1, 6))
     dt, tdt, ft = ((np.float64, torch.float64, 1), (np.float32, torch.float32, 0))[t % 3 == 0]
-    os.environ["TPG_ZIPPER_VARIANT"] = str(int(rng.integers(0, 5)))
+    os.environ["TPG_ZIPPER_VARIANT"] = str(int(rng.choice([0, 3])))
     mode = t % 3
     if mode == 0: os.environ.pop("TPG_FILL_FUSED", None)
     else: os.environ["TPG_FILL_FUSED"] = str(mode - 1)
+    lib.tpg_reload_config()                                  # the library reads its knobs once
     specs = [(int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([1, -1, 3]))) for _ in range(nf)]
     if t % 11 == 5: nf = int(rng.integers(17, 40)); specs = [(int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([1, -1]))) for _ in range(nf)]   # > TPG_MAX_FIELDS
     shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
