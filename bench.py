@@ -165,7 +165,19 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            comm = osg.RcclComm.from_torch()                        # the exchange itself is librccl through the C ABI
+            # the exchange itself is librccl through the C ABI (tpg_halo_exchange_y); should its communicator fail to come up
+            # on ANY rank, every rank falls back to torch.distributed's batch_isend_irecv (also RCCL) and the line says so
+            try:
+                comm = osg.RcclComm.from_torch()
+                comm_error = None
+            except Exception as e:                                  # noqa: BLE001
+                comm, comm_error = None, f"{type(e).__name__}: {e}"
+            ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.destroy(); comm = None
+            if comm is None:
+                print(f"[bench rank {rank}] tpg_comm_init_rank unavailable ({comm_error}); seam exchange over torch.distributed", file=sys.stderr)
 
     lib = _lib.lib()
     gsize = (NX, NY * world, NZ)                                   # weak scaling: 1800 rows per rank
@@ -384,7 +396,8 @@ def main():
             "overlap": "seam exchange on a side stream, concurrent with the grid build" if overlap else None,
             "exchange_ms": t_exchange,                                  # max over ranks; per seam direction: 4 fields x 9.58 MB
             "exchange_transport": None if world == 1 else ("gloo, host-staged (rehearsal: timings meaningless)" if rehearse
-                                                           else "tpg_halo_exchange_y: librccl ncclSend/ncclRecv group, packed messages"),
+                                                           else ("tpg_halo_exchange_y: librccl ncclSend/ncclRecv group, packed messages" if comm is not None
+                                                                 else "torch.distributed batch_isend_irecv (nccl = RCCL), packed messages [fallback]")),
             "seam_GBps_per_direction": (4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8 / (t_exchange * 1e-3) / 1e9) if t_exchange else None,
             "zipper_GBps": zbytes / (t_zip * 1e-3) / 1e9,
             # the periodic pass is bound by the 128-B lines it must touch, not by the bytes it needs from them:

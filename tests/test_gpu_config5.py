@@ -45,7 +45,7 @@ def _check_big_field(oracle, f, before_top, low_sum, xl, yl, sg):
     assert int(ints[:, :Ny - 1, Hx:Hx + Nx].sum()) == low_sum
     assert torch.equal(d[:, :Ny - 1, :Hx], d[:, :Ny - 1, Nx:Nx + Hx])
     assert torch.equal(d[:, :Ny - 1, Nx + Hx:], d[:, :Ny - 1, Hx:2 * Hx])
-    assert not bool((d[:, Hy:Ny - 1, :Hx] == 12345.0).any())        # sentinel gone from the x halos of interior rows
+    assert not bool((d[Hz:Hz + Nz, Hy:Ny - 1, :Hx] == 12345.0).any())   # sentinel gone from the x halos of interior rows and levels
 
 
 def test_config5_tupled_3d_fill(osg, oracle, gpu):

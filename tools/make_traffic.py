@@ -5,6 +5,7 @@ Counter unit = KiB; FETCH_SIZE is doubled (gfx950 counts 128-B read requests as 
 MI355X_MICROARCH.md 'HBM'); per-launch averages, first launch of each kernel dropped."""
 import collections
 import csv
+import hashlib
 import json
 import os
 import re
@@ -29,10 +30,13 @@ def main():
     for k in fetch:
         kernels[k] = {"fetch_bytes_raw": fetch[k], "fetch_bytes_corrected": 2 * fetch[k], "write_bytes": write.get(k, 0.0),
                       "hbm_bytes_per_launch": 2 * fetch[k] + write.get(k, 0.0)}
-    out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc2.sh) over `bench.py --steps 4 "
-                      "--warmup 1`, profiles/r01/pmc/v5_{fetch,write}_counter_collection.csv; per-launch averages (first launch "
-                      "dropped). Counter unit = KiB; FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B, "
+    src = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "csrc", "tpg_zipper.hip")
+    out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc.sh) over `bench.py --no-aux --no-fill-step "
+                      f"--steps 5 --warmup 1`: {os.path.relpath(sys.argv[1], ROOT)}, {os.path.relpath(sys.argv[2], ROOT)}; per-launch averages "
+                      "(first launch dropped). Counter unit = KiB; FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B, "
                       "MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as read.",
+           # bench.py reports `roofline.traffic` only while the kernel source is the one these counters were taken on
+           "zipper_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
            "kernels": kernels, "k_zipper_cols_bytes_per_launch": kernels["k_zipper_cols"]["hbm_bytes_per_launch"]}
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
