@@ -313,6 +313,78 @@ __global__ __launch_bounds__(256) void k_fill_fused(FieldTable ft, FusedArgs a)
     c[(long long)a.sx * jj + ii] = v;
 }
 
+
+// 16-byte form of the fused fill (rows chunkable: Hx and Nx multiples of W, 16-B aligned fields): one thread per 16-B chunk of
+// a written row instead of one per cell -- half (f64) / a quarter (f32) of the threads and index arithmetic, whole-chunk loads
+// and stores.  Same composed map as k_fill_fused; a chunk never straddles the interior / x-halo boundary (Hx % W == 0), so its
+// W elements share one wrapped base column iw0 and its mirrored source is ONE contiguous, reversed window.
+//   items of a level:  A = (Hy+1) rows from row Ny up  x  sx/W chunks (all columns, corners included)
+//                      B = the Ny+Hy-1 rows below       x  2Hx/W x-halo chunks (plain periodic copies)
+struct FusedVecArgs { int Nx, Ny, Hx, Hy, Hz, Nz, sx; long long plane; int cpr, hc, itemsA, per_level; };
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) void k_fill_fused_vec(FieldTable ft, FusedVecArgs a)
+{
+    typedef typename Vec<T, W>::aligned_t vec_t;
+    typedef typename Vec<T, W>::loose_t lvec_t;
+    const int f = blockIdx.y;
+    int item = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nlev = a.Nz + 2 * a.Hz;
+    if (item >= a.per_level * nlev) return;
+    const int lev = item / a.per_level;
+    item -= lev * a.per_level;
+    T* c = static_cast<T*>(ft.ptr[f]) + a.plane * lev;
+    if (item >= a.itemsA) {
+        // ---- B: x-halo chunk of a row below row Ny: west halo <- east interior columns, east halo <- west interior
+        item -= a.itemsA;
+        const int jj = item / a.hc, q = item - jj * a.hc;
+        const int hw = a.hc >> 1;                                   // chunks per halo side
+        T* row = c + (long long)a.sx * jj;
+        const int dst = q < hw ? q * W : a.Hx + a.Nx + (q - hw) * W;
+        const int src = q < hw ? a.Nx + q * W : a.Hx + (q - hw) * W;
+        *reinterpret_cast<vec_t*>(row + dst) = *reinterpret_cast<const vec_t*>(row + src);
+        return;
+    }
+    // ---- A: rows Ny .. Ny+Hy, every chunk of the padded row
+    const int xl = ft.xloc[f], yl = ft.yloc[f];
+    const int sgn = ft.sign[f];
+    const int jr = item / a.cpr, ch = item - jr * a.cpr;            // jr = 0: row Ny, 1..Hy: halo rows
+    const int ii0 = ch * W;                                         // parent column of the chunk's first element
+    const int i = ii0 - a.Hx + 1;                                   // its logical column
+    const bool west = ii0 < a.Hx, east = ii0 >= a.Hx + a.Nx;
+    const int iw0 = west ? i + a.Nx : (east ? i - a.Nx : i);        // wrapped into 1..Nx (whole chunk: Hx % W == 0)
+    const bool halo = west || east;
+    const bool zipped = lev >= a.Hz && lev < a.Hz + a.Nz;
+    T* rowNy = c + (long long)a.sx * (a.Ny + a.Hy - 1);
+    T* drow = rowNy + (long long)a.sx * jr;
+    const T s = (T)sgn, as = (T)(sgn < 0 ? -sgn : sgn);
+    // mirrored window of columns iw0 .. iw0+W-1: x-Center i' = Nx-iw+1, x-Face i' = Nx-iw+2 (descending in iw)
+    const int wlo = a.Nx - iw0 - W + 1 + (xl == TPG_FACE ? 1 : 0) + a.Hx;        // parent column of the window's lowest element
+    const bool wrap = (xl == TPG_FACE) && iw0 == 1;                 // i' = Nx+1 -> 1 with |sign| (:73-75, :90-92)
+    vec_t o;
+    if (zipped && jr > 0) {
+        const T* srow = rowNy - (long long)a.sx * (jr - (yl == TPG_FACE ? 1 : 0));   // row Ny-j (y-Center) / Ny-j+1 (y-Face)
+        const vec_t v = *reinterpret_cast<const lvec_t*>(srow + wlo);
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = s * v[W - 1 - e];
+        if (wrap) o[0] = as * srow[a.Hx];
+    } else if (zipped && yl == TPG_CENTER) {
+        // row Ny of a y-Center field: columns iw > Nx/2 take the substitution (interior) or its periodic image (west halo);
+        // columns iw <= Nx/2 are untouched (interior) or a plain periodic copy (east halo)      (:102, :135)
+        const bool any_hi = iw0 + W - 1 > a.Nx / 2, any_lo = iw0 <= a.Nx / 2;
+        if (!any_hi && !halo) return;
+        vec_t v = {}, pl = {};
+        if (any_hi) v = *reinterpret_cast<const lvec_t*>(rowNy + wlo);
+        if (any_lo) pl = *reinterpret_cast<const vec_t*>(rowNy + (iw0 + a.Hx - 1));
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = (iw0 + e > a.Nx / 2) ? s * v[W - 1 - e] : pl[e];
+    } else {
+        if (!halo) return;                                          // z-halo level, or row Ny of a y-Face field: periodic x only
+        o = *reinterpret_cast<const vec_t*>(drow + (iw0 + a.Hx - 1));
+    }
+    *reinterpret_cast<vec_t*>(drow + ii0) = o;
+}
+
 // ---- latitude-band message pack / unpack --------------------------------------------------------
 struct PackArgs { int sx, sy, nlev, Hy, row0; long long plane; int nfields; int chunk_elems; };
 
@@ -591,9 +663,22 @@ int tpg_fill_halo_regions(void* const fields[], int nfields, const int8_t xloc[]
                 t.nfields = n;
                 for (int f = 0; f < n; ++f) { t.ptr[f] = fields[f0 + f]; t.xloc[f] = xloc[f0 + f]; t.yloc[f] = yloc[f0 + f]; t.sign[f] = sign[f0 + f]; t.item0[f] = 0; }
                 t.item0[n] = 0;
-                dim3 grid((unsigned)((items + 255) / 256), (unsigned)n);
-                if (ft == TPG_F64) hipLaunchKernelGGL(k_fill_fused<double>, grid, dim3(256), 0, s, t, a);
-                else               hipLaunchKernelGGL(k_fill_fused<float>, grid, dim3(256), 0, s, t, a);
+                // 16-byte form wherever rows are chunkable and the fields 16-B aligned; one thread per cell otherwise
+                const int W = ft == TPG_F64 ? 2 : 4;
+                bool vec = (Hx % W == 0) && (Nx % W == 0);
+                for (int f = 0; f < n && vec; ++f) vec = ((uintptr_t)t.ptr[f] % 16) == 0;
+                if (vec) {
+                    FusedVecArgs v{ Nx, Ny, Hx, Hy, Hz, Nz, g.sx, (long long)g.sx * g.sy, g.sx / W, 2 * Hx / W, 0, 0 };
+                    v.itemsA = (Hy + 1) * v.cpr;
+                    v.per_level = v.itemsA + (Ny + Hy - 1) * v.hc;
+                    dim3 gridv((unsigned)(((long long)v.per_level * (Nz + 2 * Hz) + 255) / 256), (unsigned)n);
+                    if (ft == TPG_F64) hipLaunchKernelGGL((k_fill_fused_vec<double, 2>), gridv, dim3(256), 0, s, t, v);
+                    else               hipLaunchKernelGGL((k_fill_fused_vec<float, 4>), gridv, dim3(256), 0, s, t, v);
+                } else {
+                    dim3 grid((unsigned)((items + 255) / 256), (unsigned)n);
+                    if (ft == TPG_F64) hipLaunchKernelGGL(k_fill_fused<double>, grid, dim3(256), 0, s, t, a);
+                    else               hipLaunchKernelGGL(k_fill_fused<float>, grid, dim3(256), 0, s, t, a);
+                }
                 if ((rc = tpg::launch_status("k_fill_fused"))) return rc;
             }
             return TPG_OK;

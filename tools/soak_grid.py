@@ -17,7 +17,7 @@ for t in range(trials):
               first_pole_longitude=float(np.round(rng.uniform(-200, 380), int(rng.integers(0, 6)))),
               southernmost_latitude=float(np.round(rng.uniform(-88, 15), int(rng.integers(0, 6)))), radius=float(rng.choice([1.0, 6371e3, 3389.5e3])))
     dtype, tdt = ((np.float64, torch.float64), (np.float32, torch.float32))[t % 5 == 0]
-    os.environ["TPG_CELLS_VARIANT"] = "3" if t % 3 else "0"; _lib.lib().tpg_reload_config()
+    os.environ["TPG_CELLS_VARIANT"] = "3" if t % 3 else "0"; osg._lib.lib().tpg_reload_config()
     ref = oracle.build_grid(dtype=dtype, **kw)
     g = osg.TripolarGrid(osg.GPU(0), tdt, **kw)
     for name, r in ref.items():
