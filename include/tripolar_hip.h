@@ -29,6 +29,7 @@
  *    TPG_BUILD_NT        1 streaming stores in tpg_build_grid (default), 0 plain stores
  *    TPG_ZIPPER_VARIANT  3 column work items (default), 0 row work items (the fallback kernels, everywhere)
  *    TPG_FILL_FUSED      0 never / 1 always (where valid) use the fused small-field fill
+ *    TPG_FILL_MERGED     0 never use the merged large-field fill (zipper + periodic x in one launch)
  * The library holds no other mutable global state: a thread-local error string, the immutable knob record,
  * and the lazily bound librccl entry points (std::call_once).
  */
@@ -153,7 +154,10 @@ int tpg_periodic_x_fill(void *const fields[], int nfields,
  * 143-147,177-185), then periodic x.  Small fields (2-D free-surface / barotropic fields: fewer than 2^20
  * written cells per call) take ONE fused launch in which every written cell is computed from original
  * interior values through the composed index map; results are identical to the two-launch sequence.
- * TPG_FILL_FUSED=0 disables, =1 forces the fused form wherever Nx >= 2Hx+2 and Ny >= 2Hy+2. */
+ * TPG_FILL_FUSED=0 disables, =1 forces the fused form wherever Nx >= 2Hx+2 and Ny >= 2Hy+2.
+ * Large fields with 16-B chunkable rows and Hy <= 8 take ONE merged launch as well: column-chunk fold blocks that also
+ * write the corner cells (composed map) beside periodic-x blocks for all other rows (TPG_FILL_MERGED=0 disables);
+ * everything else runs tpg_zipper_fill then tpg_periodic_x_fill. */
 int tpg_fill_halo_regions(void *const fields[], int nfields,
                           const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                           int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,

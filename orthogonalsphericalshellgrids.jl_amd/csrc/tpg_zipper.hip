@@ -385,6 +385,88 @@ __global__ __launch_bounds__(256) void k_fill_fused_vec(FieldTable ft, FusedVecA
     *reinterpret_cast<vec_t*>(drow + ii0) = o;
 }
 
+
+// ---- merged fill for large fields: the whole fill_halo_regions! (zipper -> periodic x) in ONE launch -----------------
+// Blocks [0, blocksA): the column kernel over the FULL padded width -- a thread owns one 16-B column chunk of one
+// (field, level), x-halo chunks included, and writes rows Ny .. Ny+Hy of it: halo rows through the composed map
+// (wrapped base column iw0, mirrored source window: the cell the periodic pass would have copied from the folded row),
+// row Ny as the substitution / its periodic image (y-Center) or the plain periodic copy of its x halos (y-Face).
+// Blocks [blocksA, ..): the periodic pass of every other (level, row): all rows of the z-halo levels, rows below row Ny of
+// the folded levels.  The two parts touch disjoint cells and read only interior cells nobody writes (except the discarded
+// top element of an x-Face wrap window), so they need no order: one kernel boundary less per fill, and the fold's launch
+// ramp and tail hide under the periodic pass's stream.  Same geometry conditions as k_fill_fused.
+struct MergedArgs { int Nx, Ny, Hx, Hy, Hz, Nz, sx, sy; long long plane; int cprA, hw; unsigned blocksA; long long rowsB; };
+
+template <typename T, int W, int HY>
+__global__ __launch_bounds__(256) void k_fill_merged(FieldTable ft, MergedArgs a)
+{
+    typedef typename Vec<T, W>::aligned_t vec_t;
+    typedef typename Vec<T, W>::loose_t lvec_t;
+    const int f = blockIdx.y;
+    T* __restrict__ c = static_cast<T*>(ft.ptr[f]);
+    if (blockIdx.x >= a.blocksA) {
+        // ---- B: periodic x of one (level, row): chunk v of the west halo and of the east halo
+        const long long item = (long long)(blockIdx.x - a.blocksA) * 256 + threadIdx.x;
+        if (item >= a.rowsB * a.hw) return;
+        const long long row = item / a.hw;                          // over (level, parent row)
+        const int v = (int)(item - row * a.hw);
+        const int lev = (int)(row / a.sy), jj = (int)(row - (long long)lev * a.sy);
+        if (lev >= a.Hz && lev < a.Hz + a.Nz && jj >= a.Ny + a.Hy - 1) return;      // rows Ny.. of a folded level: part A
+        vec_t* r = reinterpret_cast<vec_t*>(c + row * a.sx);
+        const int nxc = a.Nx / W, hxc = a.Hx / W;
+        const vec_t w = r[nxc + v], e = r[hxc + v];
+        r[v] = w;
+        r[hxc + nxc + v] = e;
+        return;
+    }
+    // ---- A
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= a.Nz * a.cprA) return;
+    const int xl = ft.xloc[f], yl = ft.yloc[f];
+    const int sgn = ft.sign[f];
+    const int kk = item / a.cprA, ch = item - kk * a.cprA;
+    const int ii0 = ch * W;                                         // parent column of the chunk
+    const int i = ii0 - a.Hx + 1;
+    const bool west = ii0 < a.Hx, east = ii0 >= a.Hx + a.Nx;
+    const int iw0 = west ? i + a.Nx : (east ? i - a.Nx : i);        // wrapped into 1..Nx
+    const bool halo = west || east;
+    T* lvl = c + a.plane * (kk + a.Hz);                             // parent (column 0, row 0) of level k = kk+1
+    const long long sx = a.sx;
+    const int prow_ny = a.Ny + a.Hy - 1;
+    const int ysh = (yl == TPG_FACE) ? 1 : 0;
+    const int wlo = a.Nx - iw0 - W + 1 + (xl == TPG_FACE ? 1 : 0) + a.Hx;     // parent column of the mirrored window
+    const bool wrap = (xl == TPG_FACE) && iw0 == 1;
+    T* rowNy = lvl + sx * prow_ny;
+    vec_t v[HY];
+    T w0[HY];
+#pragma unroll
+    for (int jr = 1; jr <= HY; ++jr) {
+        const T* row = lvl + sx * (prow_ny - jr + ysh);
+        v[jr - 1] = __builtin_nontemporal_load(reinterpret_cast<const lvec_t*>(row + wlo));
+        w0[jr - 1] = wrap ? row[a.Hx] : (T)0;
+    }
+    const bool any_hi = (yl == TPG_CENTER) && (iw0 + W - 1 > a.Nx / 2);
+    const bool need_pl = (yl == TPG_CENTER) ? ((iw0 <= a.Nx / 2) && (halo || any_hi)) : halo;
+    vec_t vf = {}, pl = {};
+    if (any_hi) vf = *reinterpret_cast<const lvec_t*>(rowNy + wlo);
+    if (need_pl) pl = *reinterpret_cast<const vec_t*>(rowNy + (iw0 + a.Hx - 1));
+    const T s = (T)sgn, as = (T)(sgn < 0 ? -sgn : sgn);
+#pragma unroll
+    for (int jr = 1; jr <= HY; ++jr) {
+        vec_t o;
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = s * v[jr - 1][W - 1 - e];
+        if (wrap) o[0] = as * w0[jr - 1];
+        *reinterpret_cast<vec_t*>(rowNy + sx * jr + ii0) = o;
+    }
+    if (any_hi || need_pl) {
+        vec_t o;
+#pragma unroll
+        for (int e = 0; e < W; ++e) o[e] = (any_hi && iw0 + e > a.Nx / 2) ? s * vf[W - 1 - e] : pl[e];
+        *reinterpret_cast<vec_t*>(rowNy + ii0) = o;
+    }
+}
+
 // ---- latitude-band message pack / unpack --------------------------------------------------------
 struct PackArgs { int sx, sy, nlev, Hy, row0; long long plane; int nfields; int chunk_elems; };
 
@@ -510,6 +592,24 @@ int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t 
     else if (vec) TPG_LAUNCH((k_zipper_vec<T, W>), grid, dim3(256), s, ft, a);
     else          TPG_LAUNCH((k_zipper_scalar<T>), grid, dim3(256), s, ft, a);
     return tpg::launch_status("k_zipper");
+}
+
+template <typename T, int W>
+int merged_batch(const FieldTable& t, const MergedArgs& a, int n, int Hy, hipStream_t s)
+{
+    const long long itemsB = a.rowsB * a.hw;
+    dim3 grid(a.blocksA + (unsigned)((itemsB + 255) / 256), (unsigned)n);
+    switch (Hy) {
+    case 1: hipLaunchKernelGGL((k_fill_merged<T, W, 1>), grid, dim3(256), 0, s, t, a); break;
+    case 2: hipLaunchKernelGGL((k_fill_merged<T, W, 2>), grid, dim3(256), 0, s, t, a); break;
+    case 3: hipLaunchKernelGGL((k_fill_merged<T, W, 3>), grid, dim3(256), 0, s, t, a); break;
+    case 4: hipLaunchKernelGGL((k_fill_merged<T, W, 4>), grid, dim3(256), 0, s, t, a); break;
+    case 5: hipLaunchKernelGGL((k_fill_merged<T, W, 5>), grid, dim3(256), 0, s, t, a); break;
+    case 6: hipLaunchKernelGGL((k_fill_merged<T, W, 6>), grid, dim3(256), 0, s, t, a); break;
+    case 7: hipLaunchKernelGGL((k_fill_merged<T, W, 7>), grid, dim3(256), 0, s, t, a); break;
+    default: hipLaunchKernelGGL((k_fill_merged<T, W, 8>), grid, dim3(256), 0, s, t, a); break;
+    }
+    return tpg::launch_status("k_fill_merged");
 }
 
 }  // namespace
@@ -680,6 +780,31 @@ int tpg_fill_halo_regions(void* const fields[], int nfields, const int8_t xloc[]
                     else               hipLaunchKernelGGL(k_fill_fused<float>, grid, dim3(256), 0, s, t, a);
                 }
                 if ((rc = tpg::launch_status("k_fill_fused"))) return rc;
+            }
+            return TPG_OK;
+        }
+    }
+    // large fields: zipper (with its corner cells) + periodic x merged into one launch; TPG_FILL_MERGED=0 never
+    const int W = ft == TPG_F64 ? 2 : 4;
+    if (north_is_zipper && tpg::config().fill_merged != 0 && Hx > 0 && Hy >= 1 && Hy <= 8 && Nx >= 2 * Hx + 2 && Ny >= 2 * Hy + 2
+        && Hx % W == 0 && Nx % W == 0 && (long long)Nz * ((Nx + 2 * Hx) / W) < (1ll << 31) - 256) {
+        bool aligned = fields && xloc && yloc && sign;
+        for (int f = 0; f < nfields && aligned; ++f)
+            aligned = fields[f] && ((uintptr_t)fields[f] % 16) == 0 && (xloc[f] == TPG_CENTER || xloc[f] == TPG_FACE)
+                      && (yloc[f] == TPG_CENTER || yloc[f] == TPG_FACE);
+        if (aligned && nfields >= 1 && !(rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft))) {
+            Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
+            MergedArgs a{ Nx, Ny, Hx, Hy, Hz, Nz, g.sx, g.sy, g.plane, g.sx / W, Hx / W, 0, (long long)g.sy * (Nz + 2 * Hz) };
+            a.blocksA = (unsigned)(((long long)Nz * a.cprA + 255) / 256);
+            hipStream_t s = tpg::as_stream(stream);
+            for (int f0 = 0; f0 < nfields; f0 += TPG_MAX_FIELDS) {
+                const int n = nfields - f0 < TPG_MAX_FIELDS ? nfields - f0 : TPG_MAX_FIELDS;
+                FieldTable t;
+                t.nfields = n;
+                for (int f = 0; f < n; ++f) { t.ptr[f] = fields[f0 + f]; t.xloc[f] = xloc[f0 + f]; t.yloc[f] = yloc[f0 + f]; t.sign[f] = sign[f0 + f]; t.item0[f] = 0; }
+                t.item0[n] = 0;
+                rc = (ft == TPG_F64) ? merged_batch<double, 2>(t, a, n, Hy, s) : merged_batch<float, 4>(t, a, n, Hy, s);
+                if (rc) return rc;
             }
             return TPG_OK;
         }

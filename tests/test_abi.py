@@ -95,3 +95,16 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".jl")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.replace("oracle/ as test infrastructure", ""), os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/tripolar_hip.h must compile as C99 with no C++ or HIP types (the boundary a Julia ccall / cgo / JNI stub binds)"""
+    import subprocess
+    names = declared_symbols()
+    src = tmp_path / "abi.c"
+    src.write_text('#include "tripolar_hip.h"\n'
+                   + "typedef void (*fn)(void);\nstatic fn table[] = {" + ", ".join(f"(fn){n}" for n in names) + "};\n"
+                   + "int main(void) { tpg_params p = {0}; (void)p; return sizeof(table) == 0 || TPG_NUM_ARRAYS != 20 || TPG_COMM_ID_BYTES != 128; }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "abi.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

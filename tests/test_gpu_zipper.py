@@ -91,22 +91,25 @@ class _Knob:
 
 @pytest.fixture
 def fused_knob(osg):
-    saved = os.environ.get("TPG_FILL_FUSED")
+    saved = {k: os.environ.get(k) for k in ("TPG_FILL_FUSED", "TPG_FILL_MERGED")}
     yield _Knob(osg._lib.lib())
-    if saved is None:
-        os.environ.pop("TPG_FILL_FUSED", None)
-    else:
-        os.environ["TPG_FILL_FUSED"] = saved
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     osg._lib.lib().tpg_reload_config()
 
 
-@pytest.mark.parametrize("fused", ["0", "1"], ids=["two-launch", "fused"])
+@pytest.mark.parametrize("fused,merged", [("0", "0"), ("1", "0"), ("0", "1")], ids=["two-launch", "fused", "merged"])
 @pytest.mark.parametrize("size,halo", GEOMS, ids=[f"{s}-{h}" for s, h in GEOMS])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_fill_halo_regions_parity(osg, oracle, gpu, fused_knob, size, halo, dtype, fused):
-    """zipper -> periodic x as two launches, and as the single fused launch small fields take by default
-    (geometries the fused kernel does not cover -- Nx < 2 Hx + 2, Ny < 2 Hy + 2 -- fall back by themselves)"""
+def test_fill_halo_regions_parity(osg, oracle, gpu, fused_knob, size, halo, dtype, fused, merged):
+    """zipper -> periodic x as two launches, as the single fused launch small fields take by default, and as the single
+    merged launch large fields take (geometries a single-launch form does not cover -- Nx < 2 Hx + 2, Ny < 2 Hy + 2,
+    unchunkable rows, Hy > 8 for the merged form -- fall back by themselves)"""
     fused_knob["TPG_FILL_FUSED"] = fused
+    fused_knob["TPG_FILL_MERGED"] = merged
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     grid = osg.TripolarGrid(osg.GPU(0), tdt, size=size, halo=halo)
     specs = [(xl, yl, sg) for xl, yl in LOCS for sg in (1, -1)]
@@ -271,14 +274,18 @@ def test_randomised_geometries_against_the_oracle(osg, oracle, gpu):
 
 
 def test_fused_fill_randomised_against_the_oracle(osg, oracle, gpu, fused_knob):
-    """60 random geometries through tpg_fill_halo_regions with the fused kernel forced on (and the automatic
-    choice): whole padded array bit-identical to the oracle's zipper -> periodic x sequence"""
+    """90 random geometries through tpg_fill_halo_regions with the fused kernel forced on, the merged kernel forced on, and
+    the automatic choice: whole padded array bit-identical to the oracle's zipper -> periodic x sequence"""
     lib = osg._lib.lib()
     rng = np.random.default_rng(4242)
-    for trial in range(60):
+    for trial in range(90):
         fused_knob["TPG_FILL_FUSED"] = "1"
+        fused_knob["TPG_FILL_MERGED"] = "0"
         if trial % 3 == 2:
             fused_knob.pop("TPG_FILL_FUSED")
+        if trial % 3 == 1:                                   # the merged large-field launch on the same random geometries
+            fused_knob["TPG_FILL_FUSED"] = "0"
+            fused_knob["TPG_FILL_MERGED"] = "1"
         Nx = int(rng.choice([4, 6, 10, 12, 14, 16, 30, 64, 66, 128, 130, 258]))
         Ny = int(rng.integers(2, 30))
         Nz = int(rng.integers(1, 4))

@@ -21,6 +21,7 @@ for t in range(trials):
     mode = t % 3
     if mode == 0: os.environ.pop("TPG_FILL_FUSED", None)
     else: os.environ["TPG_FILL_FUSED"] = str(mode - 1)
+    os.environ["TPG_FILL_MERGED"] = str(int(rng.integers(0, 2)))
     lib.tpg_reload_config()                                  # the library reads its knobs once
     specs = [(int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([1, -1, 3]))) for _ in range(nf)]
     if t % 11 == 5: nf = int(rng.integers(17, 40)); specs = [(int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([1, -1]))) for _ in range(nf)]   # > TPG_MAX_FIELDS
