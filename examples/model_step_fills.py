@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Next-row sketch (SURVEY.md 8f-1, config 5 scale): the halo fills of ONE baroclinic step of a hydrostatic
-model on a 1/24-degree, 75-level tripolar grid, single MI355X (the fields alone are ~125 GB of the 288 GB HBM).
+"""SURVEY.md 8f-1, BASELINE config 5: the halo fills of ONE baroclinic step of a hydrostatic model on the
+1/24-degree, 100-level tripolar grid, single MI355X (the five 3-D fields alone are 162 GB of the 288 GB HBM).
+The same fills are parity-tested against the oracle in tests/test_gpu_config5.py and timed in bench.py's `fill_step`.
 
 Per step (examples/bickley_jet.jl:44-89 and test/runtests.jl:46-77 build this kind of model):
-  * one tupled fill of the 3-D prognostic fields (u, v, T, S, c) -- one zipper launch + one periodic launch;
-  * `substeps` fills of the split-explicit free surface's 2-D fields (eta, U, V) -- one fused launch each,
-    replayed from a HIP graph.
+  * one tupled fill of the 3-D prognostic fields (u, v, T, S, c) -- ONE merged launch (fold + corners + periodic x);
+  * `substeps` fills of the split-explicit free surface's 2-D fields (eta, U, V), which live on a grid whose north
+    halo is extended to substeps + 1 rows (test/runtests.jl:61-71) -- one fused launch each, replayed from a HIP graph.
 Prints the time of each part and what bounds it.  Run on an MI355X:  python examples/model_step_fills.py
 """
 import os
@@ -16,7 +17,7 @@ import torch
 
 import orthogonalsphericalshellgrids.jl_amd as osg
 
-SIZE = (8640, 4320, 75)
+SIZE = (8640, 4320, 100)
 SUBSTEPS = 30
 
 
@@ -36,9 +37,10 @@ def main():
     Nx, Ny, Nz = SIZE
     u, v = osg.XFaceField(grid), osg.YFaceField(grid)
     T, S, c = osg.CenterField(grid), osg.CenterField(grid), osg.CenterField(grid)
-    eta = osg.Field((osg.Center, osg.Center, None), grid)
-    U = osg.Field((osg.Face, osg.Center, None), grid)
-    V = osg.Field((osg.Center, osg.Face, None), grid)
+    ext = osg.with_halo((4, SUBSTEPS + 1, 4), osg.TripolarGrid(size=(Nx, Ny, 1)))      # the free surface's extended-halo grid
+    eta = osg.Field((osg.Center, osg.Center, None), ext)
+    U = osg.Field((osg.Face, osg.Center, None), ext)
+    V = osg.Field((osg.Center, osg.Face, None), ext)
     for f in (u, v, T, S, c, eta, U, V):
         f.interior().uniform_(-1, 1)
     gb = sum(f.data.numel() * 8 for f in (u, v, T, S, c)) / 1e9

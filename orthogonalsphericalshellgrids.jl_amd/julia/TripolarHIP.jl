@@ -28,8 +28,7 @@ using Oceananigans.DistributedComputations: Distributed, local_size, ranks, conc
 using OffsetArrays
 using Adapt
 
-import Oceananigans.BoundaryConditions: bc_str, apply_y_north_bc!, regularize_field_boundary_conditions,
-                                        fill_south_and_north_halo!            # [recalled] launcher, see section 5
+import Oceananigans.BoundaryConditions: bc_str, apply_y_north_bc!, regularize_field_boundary_conditions
 import Oceananigans.Fields: Field, validate_boundary_condition_location
 import Oceananigans.Grids: x_domain, y_domain, with_halo
 import Oceananigans.DistributedComputations: reconstruct_global_grid
@@ -332,6 +331,12 @@ function zipper_fill!(fields, bcs, locs, grid; periodic_x::Bool = false)
     return nothing
 end
 
+# The launcher's name is Oceananigans-internal and version dependent: the methods are added only where it exists, so that the
+# rest of the module (grid construction, metadata, exchange, geometry) loads on any version; `zipper_fill!` stays callable.
+@static if isdefined(Oceananigans.BoundaryConditions, :fill_south_and_north_halo!)
+
+import Oceananigans.BoundaryConditions: fill_south_and_north_halo!
+
 # single field: what fill_halo_regions!(field) reaches
 function fill_south_and_north_halo!(c, south_bc, north_bc::ZBC, size, offset, loc, arch, grid::Union{TRG, DTRG}, args...; kwargs...)
     # the south side stays Oceananigans' (the reference's own fills leave it `nothing`, src/tripolar_grid.jl:148)
@@ -349,6 +354,8 @@ function fill_south_and_north_halo!(c::NTuple, south_bc, north_bc::NTuple{N, <:Z
     zipper_fill!(c, north_bc, loc, grid)
     return nothing
 end
+
+end # @static if: launcher present
 
 # ---------------------------------------------------------------------------------------------------------------------
 # 6. Latitude-band seam exchange over RCCL                         src/distributed_tripolar_grid.jl:171,195 (transport)
