@@ -322,6 +322,48 @@ def main():
         del flush
         for fid, f in enumerate(fields):                                        # the copy probe left unfolded halos behind
             _lib.check(lib.tpg_fill_synthetic(f.data_ptr(), 0x5EED + fid, 12345.0, NX, NY, NZ, H, H, H, _lib.TPG_F64, None))
+        # BASELINE config 2: the 1/4 degree (1440 x 720) Float64 metric precompute alone, 20 back-to-back builds
+        p2 = _lib.TpgParams(1440, 720, 1, H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F64, 1, 720, 0)
+        out2 = [torch.empty((720 + 2 * H, 1440 + 2 * H), dtype=torch.float64, device=dev) for _ in _lib.ARRAY_NAMES]
+        ptr2 = _lib.ptr_table(out2)
+        ws2 = torch.empty(int(lib.tpg_build_grid_workspace_bytes(C.byref(p2))), dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            _lib.check(lib.tpg_build_grid(C.byref(p2), ptr2, ws2.data_ptr(), ws2.numel(), stream))
+        b0, b1 = ev(), ev()
+        b0.record()
+        for _ in range(20):
+            _lib.check(lib.tpg_build_grid(C.byref(p2), ptr2, ws2.data_ptr(), ws2.numel(), stream))
+        b1.record(); torch.cuda.synchronize()
+        us2 = b0.elapsed_time(b1) / 20 * 1e3
+        aux["config2_quarter_degree_build"] = {"size": [1440, 720, 1], "us_per_build": us2, "cells_per_s": 1440 * 720 / (us2 * 1e-6),
+                                               "store_GBps": 160.0 * 1448 * 728 / (us2 * 1e-6) / 1e9}
+        del out2, ws2
+        # SURVEY 8(f-4) geometry utilities at the bench's own size, on the grid arrays the warm-up build just has to produce
+        _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
+        arr = dict(zip(_lib.ARRAY_NAMES, out))
+        angle = torch.empty((NY, NX), dtype=torch.float64, device=dev)
+        uo, vo = torch.zeros_like(fields[0]), torch.zeros_like(fields[0])
+
+        def timed_us(fn, reps):
+            fn(); torch.cuda.synchronize()
+            t0_, t1_ = ev(), ev()
+            t0_.record()
+            for _ in range(reps):
+                fn()
+            t1_.record(); torch.cuda.synchronize()
+            return t0_.elapsed_time(t1_) / reps * 1e3
+
+        t_ang = timed_us(lambda: _lib.check(lib.tpg_nonorthogonality_angle(arr["lambda_ff"].data_ptr(), arr["phi_ff"].data_ptr(), None,
+                                                                           angle.data_ptr(), NX, NY, H, H, _lib.TPG_F64, stream)), 20)
+        t_rot = timed_us(lambda: _lib.check(lib.tpg_convert_frame(arr["phi_cf"].data_ptr(), arr["phi_fc"].data_ptr(), arr["dy_cc"].data_ptr(),
+                                                                  arr["dx_cc"].data_ptr(), fields[0].data_ptr(), fields[1].data_ptr(),
+                                                                  uo.data_ptr(), vo.data_ptr(), 0, *geom, _lib.TPG_F64, stream)), 5)
+        rot_bytes = 4 * NX * NY * NZ * 8                                        # 2 fields read + 2 written, interior cells
+        aux["geometry_utilities"] = {
+            "nonorthogonality_angle_us": t_ang, "nonorthogonality_max_abs_deg_unmasked": float(angle.abs().max()),
+            "convert_frame_us": t_rot, "convert_frame_algorithmic_bytes": rot_bytes,
+            "convert_frame_frac_of_hbm_peak": rot_bytes / (t_rot * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+        del angle, uo, vo
     fill_step = None
     if world == 1 and not args.no_fill_step:
         fill_step = fill_step_config5(torch, osg, _lib, dev)

@@ -57,6 +57,7 @@ template <> __device__ __forceinline__ double root<double>(double x) { return sq
 template <> __device__ __forceinline__ float root<float>(float x) { return sqrtf(x); }
 
 struct FrameArgs { int Nx, Ny, Nz, Hx, Hy, Hz, sx; long long plane; int to_native; };
+constexpr int ZCH = 16;                                        // levels per thread of k_convert_frame
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_convert_frame(const T* __restrict__ phi_cf, const T* __restrict__ phi_fc,
@@ -73,11 +74,83 @@ __global__ __launch_bounds__(256) void k_convert_frame(const T* __restrict__ phi
     const T vt = -((phi_fc[c2 + 1] - phi_fc[c2]) * d2r) / dx_cc[c2];            // :20-24
     const T U = root<T>(ut * ut + vt * vt);                                     // :26
     const T d1 = ut / U, d2 = vt / U;                                           // :28-29
-    for (int k = blockIdx.z; k < a.Nz; k += gridDim.z) {
-        const long long c3 = c2 + a.plane * (k + a.Hz);
+    // a thread owns ZCH consecutive levels of its column: the direction cosines (2 divisions + sqrt + 2 divisions) are
+    // paid once per ZCH cells, and 4 levels of loads are in flight before the first store
+    const int k0 = blockIdx.z * ZCH, k1 = k0 + ZCH < a.Nz ? k0 + ZCH : a.Nz;
+    long long c3 = c2 + a.plane * (k0 + a.Hz);
+    int k = k0;
+    for (; k + 4 <= k1; k += 4, c3 += 4 * a.plane) {
+        T p[4], q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { p[e] = __builtin_nontemporal_load(u + c3 + e * a.plane); q[e] = __builtin_nontemporal_load(v + c3 + e * a.plane); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            T x, y;
+            if (a.to_native) { x = p[e] * d1 + q[e] * d2; y = p[e] * d2 - q[e] * d1; }     // :54
+            else             { x = p[e] * d1 - q[e] * d2; y = p[e] * d2 + q[e] * d1; }     // :31
+            __builtin_nontemporal_store(x, uo + c3 + e * a.plane); __builtin_nontemporal_store(y, vo + c3 + e * a.plane);
+        }
+    }
+    for (; k < k1; ++k, c3 += a.plane) {
         const T p = u[c3], q = v[c3];
-        if (a.to_native) { uo[c3] = p * d1 + q * d2; vo[c3] = p * d2 - q * d1; }   // :54
-        else             { uo[c3] = p * d1 - q * d2; vo[c3] = p * d2 + q * d1; }   // :31
+        if (a.to_native) { uo[c3] = p * d1 + q * d2; vo[c3] = p * d2 - q * d1; }
+        else             { uo[c3] = p * d1 - q * d2; vo[c3] = p * d2 + q * d1; }
+    }
+}
+
+// 16-byte form: a thread owns W adjacent columns (2 doubles / 4 floats) of ZCH consecutive levels -- W sets of direction
+// cosines, 16-B streaming loads and stores (Nx and Hx multiples of W, 16-B aligned arrays; otherwise the scalar kernel)
+template <typename T, int W>
+__global__ __launch_bounds__(256) void k_convert_frame_vec(const T* __restrict__ phi_cf, const T* __restrict__ phi_fc,
+                                                           const T* __restrict__ dy_cc, const T* __restrict__ dx_cc,
+                                                           const T* __restrict__ u, const T* __restrict__ v,
+                                                           T* __restrict__ uo, T* __restrict__ vo, FrameArgs a)
+{
+    typedef T vec_t __attribute__((ext_vector_type(W)));
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * W + 1;          // first of the W columns
+    const int j = blockIdx.y + 1;
+    if (i > a.Nx) return;
+    const long long c2 = (long long)(i + a.Hx - 1) + (long long)a.sx * (j + a.Hy - 1);
+    const T d2r = (T)kDeg2Rad;
+    T d1[W], d2[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        const T ut = ((phi_cf[c2 + e + a.sx] - phi_cf[c2 + e]) * d2r) / dy_cc[c2 + e];
+        const T vt = -((phi_fc[c2 + e + 1] - phi_fc[c2 + e]) * d2r) / dx_cc[c2 + e];
+        const T U = root<T>(ut * ut + vt * vt);
+        d1[e] = ut / U; d2[e] = vt / U;
+    }
+    const int k0 = blockIdx.z * ZCH, k1 = k0 + ZCH < a.Nz ? k0 + ZCH : a.Nz;
+    long long c3 = c2 + a.plane * (k0 + a.Hz);
+    int k = k0;
+    for (; k + 4 <= k1; k += 4, c3 += 4 * a.plane) {
+        vec_t p[4], q[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            p[l] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(u + c3 + l * a.plane));
+            q[l] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(v + c3 + l * a.plane));
+        }
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            vec_t x, y;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                if (a.to_native) { x[e] = p[l][e] * d1[e] + q[l][e] * d2[e]; y[e] = p[l][e] * d2[e] - q[l][e] * d1[e]; }
+                else             { x[e] = p[l][e] * d1[e] - q[l][e] * d2[e]; y[e] = p[l][e] * d2[e] + q[l][e] * d1[e]; }
+            }
+            __builtin_nontemporal_store(x, reinterpret_cast<vec_t*>(uo + c3 + l * a.plane));
+            __builtin_nontemporal_store(y, reinterpret_cast<vec_t*>(vo + c3 + l * a.plane));
+        }
+    }
+    for (; k < k1; ++k, c3 += a.plane) {
+        const vec_t p = *reinterpret_cast<const vec_t*>(u + c3), q = *reinterpret_cast<const vec_t*>(v + c3);
+        vec_t x, y;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            if (a.to_native) { x[e] = p[e] * d1[e] + q[e] * d2[e]; y[e] = p[e] * d2[e] - q[e] * d1[e]; }
+            else             { x[e] = p[e] * d1[e] - q[e] * d2[e]; y[e] = p[e] * d2[e] + q[e] * d1[e]; }
+        }
+        *reinterpret_cast<vec_t*>(uo + c3) = x; *reinterpret_cast<vec_t*>(vo + c3) = y;
     }
 }
 
@@ -112,8 +185,23 @@ int tpg_convert_frame(const void* phi_cf, const void* phi_fc, const void* dy_cc,
     if (Ny > 65535) { tpg::set_error("Ny > 65535"); return TPG_ERR_UNSUPPORTED; }
     tpg::Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
     FrameArgs a{ Nx, Ny, Nz, Hx, Hy, Hz, g.sx, g.plane, to_native ? 1 : 0 };
-    dim3 grid((Nx + 255) / 256, Ny, Nz < 64 ? Nz : 64);
     hipStream_t s = tpg::as_stream(stream);
+    const int W = ft == TPG_F64 ? 2 : 4;
+    bool vec = (Nx % W == 0) && (Hx % W == 0);
+    for (const void* q : { u, v, (const void*)u_out, (const void*)v_out }) vec = vec && ((uintptr_t)q % 16) == 0;
+    if (vec) {
+        dim3 grid((Nx / W + 255) / 256, Ny, (Nz + ZCH - 1) / ZCH);
+        if (ft == TPG_F64)
+            hipLaunchKernelGGL((k_convert_frame_vec<double, 2>), grid, dim3(256), 0, s, static_cast<const double*>(phi_cf), static_cast<const double*>(phi_fc),
+                               static_cast<const double*>(dy_cc), static_cast<const double*>(dx_cc), static_cast<const double*>(u),
+                               static_cast<const double*>(v), static_cast<double*>(u_out), static_cast<double*>(v_out), a);
+        else
+            hipLaunchKernelGGL((k_convert_frame_vec<float, 4>), grid, dim3(256), 0, s, static_cast<const float*>(phi_cf), static_cast<const float*>(phi_fc),
+                               static_cast<const float*>(dy_cc), static_cast<const float*>(dx_cc), static_cast<const float*>(u),
+                               static_cast<const float*>(v), static_cast<float*>(u_out), static_cast<float*>(v_out), a);
+        return tpg::launch_status("k_convert_frame_vec");
+    }
+    dim3 grid((Nx + 255) / 256, Ny, (Nz + ZCH - 1) / ZCH);
     if (ft == TPG_F64)
         hipLaunchKernelGGL(k_convert_frame<double>, grid, dim3(256), 0, s, static_cast<const double*>(phi_cf), static_cast<const double*>(phi_fc),
                            static_cast<const double*>(dy_cc), static_cast<const double*>(dx_cc), static_cast<const double*>(u),

@@ -39,6 +39,7 @@ def test_bench_prints_one_contract_line(gpu):
     # cold and warm zipper launch durations, and the same-shape copy ceiling beside them
     assert 0 < d["zipper_warm_ms"] <= d["zipper_cold_dirty_ms"] * 1.5 and d["zipper_cold_ms"] > 0 and d["zipper_copy_ceiling_ms"] > 0
     assert r["copy_ceiling_ms"] == d["zipper_copy_ceiling_ms"]
+    assert d["config2_quarter_degree_build"]["cells_per_s"] > 1e9
     assert "prewarm_steps" not in d                  # exactly W warm-up steps
     assert d["periodic_x_ms"] > 0 and d["exchange_ms"] is None and d["periodic_x"]["line_bytes"] == 3 * d["periodic_x"]["algorithmic_bytes"]
     # config 5: the fills of one baroclinic step at 1/24 degree x 100 levels

@@ -40,9 +40,10 @@ def test_nonorthogonality_parity(osg, oracle, gpu, size, kw, dtype):
         assert float(masked.max()) < 2.0 and float(masked.min()) > -2.0
 
 
+@pytest.mark.parametrize("nz,halo", [(3, (4, 4, 2)), (21, (4, 4, 4)), (5, (3, 2, 1))], ids=["16B", "16B-21-levels", "scalar"])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-def test_frame_conversion_parity(osg, oracle, gpu, dtype):
-    size, halo = (180, 90, 3), (4, 4, 2)                                  # the example's grid (:58), 3 levels
+def test_frame_conversion_parity(osg, oracle, gpu, dtype, nz, halo):
+    size = (180, 90, nz)                                                  # the example's grid (:58)
     grid = osg.TripolarGrid(osg.GPU(0), dtype, size=size, halo=halo, north_poles_latitude=35)
     u, v = osg.CenterField(grid), osg.CenterField(grid)
     rng = np.random.default_rng(9)
