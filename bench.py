@@ -366,6 +366,8 @@ def main():
         del angle, uo, vo
     fill_step = None
     if world == 1 and not args.no_fill_step:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()                                    # hand the auxiliary buffers back before sizing 162 GB of fields
         fill_step = fill_step_config5(torch, osg, _lib, dev)
 
     # ---- W warm-up steps, K timed steps ------------------------------------------------------------------------------------
