@@ -21,7 +21,7 @@ constexpr double kRad2Deg = 0x1.ca5dc1a63c1f8p+5;          // 180 / Float64(pi) 
 struct V3 { double x, y, z; };
 
 template <typename T>
-__device__ __forceinline__ V3 node(const T* __restrict__ lam, const T* __restrict__ phi, long long idx)
+__device__ __forceinline__ V3 node_vector(const T* __restrict__ lam, const T* __restrict__ phi, long long idx)
 {
     double sl, cl, sp, cp;
     sincosd((double)lam[idx], sl, cl);
@@ -29,19 +29,33 @@ __device__ __forceinline__ V3 node(const T* __restrict__ lam, const T* __restric
     return V3{ cl * cp, sl * cp, sp };                       // lat_lon_to_cartesian(phi, lambda, 1)
 }
 
+// A block of 64 x NR threads evaluates one node per thread (the expensive part: two sincosd), parks the unit vectors in
+// LDS and, after one barrier, every thread that owns a cell (lanes 0..62, rows 0..NR-2: tiles overlap by one column and one
+// row) forms its two chords from its own node and the east / north neighbour's: 63 x (NR-1) cells from 64 x NR node
+// evaluations instead of three evaluations per cell.
+constexpr int NR = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void k_nonorthogonality(const T* __restrict__ lam, const T* __restrict__ phi,
-                                                          const uint8_t* __restrict__ immersed, double* __restrict__ angle,
-                                                          int Nx, int Ny, int Hx, int Hy)
+__global__ __launch_bounds__(64 * NR) void k_nonorthogonality(const T* __restrict__ lam, const T* __restrict__ phi,
+                                                              const uint8_t* __restrict__ immersed, double* __restrict__ angle,
+                                                              int Nx, int Ny, int Hx, int Hy)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;  // 1-based
-    const int j = blockIdx.y + 1;
-    if (i > Nx) return;
+    __shared__ double P[3][NR][64];
+    const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const int i = blockIdx.x * 63 + lane + 1;                    // 1-based node / cell column
+    const int j = blockIdx.y * (NR - 1) + p + 1;
+    const bool node = i <= Nx && j <= Ny;
+    V3 p0 = { 0.0, 0.0, 0.0 };
+    if (node) {
+        const long long c = (long long)(i + Hx - 1) + (long long)(Nx + 2 * Hx) * (j + Hy - 1);
+        p0 = node_vector(lam, phi, c);
+    }
+    P[0][p][lane] = p0.x; P[1][p][lane] = p0.y; P[2][p][lane] = p0.z;
+    __syncthreads();
+    if (!node || lane == 63 || p == NR - 1) return;              // apron column / row: the next tile owns these cells
     const long long o = (long long)(i - 1) + (long long)Nx * (j - 1);
-    if (i > Nx - 1 || j > Ny - 1) { angle[o] = 0.0; return; } // outside the (Nx-1, Ny-1) launch: zeros(size(grid)...) (:64)
-    const long long sx = Nx + 2 * Hx;
-    const long long c = (long long)(i + Hx - 1) + sx * (j + Hy - 1);
-    const V3 p0 = node(lam, phi, c), p1 = node(lam, phi, c + 1), p2 = node(lam, phi, c + sx);
+    if (i > Nx - 1 || j > Ny - 1) { angle[o] = 0.0; return; }    // outside the (Nx-1, Ny-1) launch: zeros(size(grid)...) (:64)
+    const V3 p1 = { P[0][p][lane + 1], P[1][p][lane + 1], P[2][p][lane + 1] };   // node (i+1, j)
+    const V3 p2 = { P[0][p + 1][lane], P[1][p + 1][lane], P[2][p + 1][lane] };   // node (i, j+1)
     const double ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z;          // v1 (:23)
     const double bx = p2.x - p0.x, by = p2.y - p0.y, bz = p2.z - p0.z;          // v2 (:24)
     const double n1 = sqrt(ax * ax + ay * ay + az * az);
@@ -164,12 +178,12 @@ int tpg_nonorthogonality_angle(const void* lambda_ff, const void* phi_ff, const 
     int rc = tpg::check_geom(Nx, Ny, 1, Hx, Hy, 0, ft);
     if (rc) return rc;
     if (!lambda_ff || !phi_ff || !angle) { tpg::set_error("null array"); return TPG_ERR_INVALID_ARGUMENT; }
-    if (Ny > 65535) { tpg::set_error("Ny > 65535"); return TPG_ERR_UNSUPPORTED; }
-    dim3 grid((Nx + 255) / 256, Ny);
+    if ((Ny + NR - 2) / (NR - 1) > 65535) { tpg::set_error("Ny too large"); return TPG_ERR_UNSUPPORTED; }
+    dim3 grid((Nx + 62) / 63, (Ny + NR - 2) / (NR - 1));
     hipStream_t s = tpg::as_stream(stream);
-    if (ft == TPG_F64) hipLaunchKernelGGL(k_nonorthogonality<double>, grid, dim3(256), 0, s, static_cast<const double*>(lambda_ff),
+    if (ft == TPG_F64) hipLaunchKernelGGL(k_nonorthogonality<double>, grid, dim3(64 * NR), 0, s, static_cast<const double*>(lambda_ff),
                                           static_cast<const double*>(phi_ff), immersed, angle, Nx, Ny, Hx, Hy);
-    else               hipLaunchKernelGGL(k_nonorthogonality<float>, grid, dim3(256), 0, s, static_cast<const float*>(lambda_ff),
+    else               hipLaunchKernelGGL(k_nonorthogonality<float>, grid, dim3(64 * NR), 0, s, static_cast<const float*>(lambda_ff),
                                           static_cast<const float*>(phi_ff), immersed, angle, Nx, Ny, Hx, Hy);
     return tpg::launch_status("k_nonorthogonality");
 }
