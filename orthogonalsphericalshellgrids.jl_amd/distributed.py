@@ -130,8 +130,15 @@ class RcclComm:
     def from_torch(cls, group=None):
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except Exception as e:                      # noqa: BLE001 -- every rank must leave the broadcast, then fail together
+                box[0] = e
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if isinstance(box[0], Exception):
+            raise RuntimeError(f"rank 0 could not draw an RCCL unique id: {box[0]}")
         return cls.create(box[0], rank, world)
 
     def destroy(self):

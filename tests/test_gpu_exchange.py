@@ -20,7 +20,7 @@ def test_rccl_seam_exchange_single_rank_loopback(gpu):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["ok"] and d["single_rank_chain_rc"] == 0
+    assert d["ok"] and d["single_rank_chain_rc"] == 0 and d["from_torch"] == [0, 1]
     assert len(d["cases"]) == 6 and all(c["bit_exact"] for c in d["cases"])
     assert {c["packed"] for c in d["cases"]} == {True, False}
 

@@ -22,8 +22,16 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     lib = _lib.lib()
-    comm = osg.RcclComm.create(osg.RcclComm.unique_id(), 0, 1)
-    out = {"ok": True, "cases": []}
+    # the bootstrap bench.py uses for N > 1: torch.distributed ("nccl" = RCCL) ferries the unique id, librccl makes the communicator
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    comm = osg.RcclComm.from_torch()
+    out = {"ok": True, "cases": [], "from_torch": [comm.rank, comm.nranks]}
     rng = np.random.default_rng(5)
     for (Nx, Ny, Nz), (Hx, Hy, Hz), nf, dt, tdt in (((48, 40, 3), (4, 4, 2), 3, np.float64, torch.float64),
                                                    ((20, 12, 2), (3, 2, 1), 2, np.float32, torch.float32),
@@ -54,12 +62,21 @@ def main():
                 want[:, Ny + Hy:] = h[:, Hy:2 * Hy]          # north halo  <- what was sent south (interior rows 1..Hy)
                 good = good and np.array_equal(d.cpu().numpy(), want)
             out["ok"] = out["ok"] and good
-            out["cases"].append({"size": [Nx, Ny, Nz], "nfields": nf, "packed": packed, "bit_exact": good, "first_call_ms": round(ms, 3)})
+            # steady-state cost of one exchange call (host + device, 5 back-to-back calls; self loop-back: no link involved)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                lib.tpg_halo_exchange_y_peers(comm.handle, 0, 0, ptrs, nf, *bp, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream)
+            torch.cuda.synchronize()
+            steady = (time.perf_counter() - t0) / 5 * 1e3
+            out["cases"].append({"size": [Nx, Ny, Nz], "nfields": nf, "packed": packed, "bit_exact": good, "first_call_ms": round(ms, 3),
+                                 "steady_call_ms": round(steady, 3)})
     # the chain rule: a one-rank chain has no seam
     d = torch.zeros((1, 12, 12), dtype=torch.float64, device=dev)
     out["single_rank_chain_rc"] = lib.tpg_halo_exchange_y(comm.handle, 0, 1, _lib.ptr_table([d]), 1, None, None, None, None, 4, 4, 1, 4, 4, 0, 1, None)
     out["ok"] = out["ok"] and out["single_rank_chain_rc"] == 0
     comm.destroy()
+    dist.destroy_process_group()
     print(json.dumps(out))
     return 0 if out["ok"] else 1
 
