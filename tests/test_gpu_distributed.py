@@ -86,3 +86,58 @@ def test_pack_unpack_roundtrip_and_layout(osg, gpu):
             assert torch.equal(f[:, rows], m)
             b[:, rows] = m
             assert torch.equal(f, b)
+
+
+def test_config4_eight_bands_at_full_size(osg, gpu):
+    """BASELINE config 4 at its real geometry: the 1/10 degree grid (3600 x 1800 x 75, halo 4, Float64) as 8 latitude bands of
+    ny = 225 rows, the four bench fields c / u / v / zeta, on ONE GPU with the 8 ranks emulated in this process (two-phase
+    loop-back transport; the RCCL leg itself is tests/test_gpu_exchange.py).
+      * every rank's band build equals rows jstart-Hy .. jend+Hy of the serially built global grid (the serial build is
+        bit-exact against the oracle at this size: tests/test_gpu_grid.py);
+      * after fill_halo_regions! on every rank (zipper on rank 7 only, periodic x, seam exchange of 4 x 9.58 MB per side) every
+        rank's padded slab equals the same rows of the serially filled global field (the serial fill is bit-exact against the
+        oracle at this size: tests/test_gpu_zipper.py::test_config3_tenth_degree_75_levels).
+    Everything is compared on the device: 17 GB of global fields + 17 GB filled copies + 18 GB of slabs."""
+    import ctypes as C
+    size, halo, R = (3600, 1800, 75), (4, 4, 4), 8
+    (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
+    lib = osg._lib.lib()
+    specs = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]
+    serial = osg.TripolarGrid(size=size, halo=halo)
+    globs, filled = [], []
+    for fid, (xl, yl, sg) in enumerate(specs):
+        loc = (osg.Face if xl else osg.Center, osg.Face if yl else osg.Center, osg.Center)
+        f = osg.Field(loc, serial)
+        assert lib.tpg_fill_synthetic(f.data.data_ptr(), 0xC4 + fid, 12345.0, *size, *halo, 1, None) == 0
+        globs.append(f.data.clone())
+        filled.append(f)
+    osg.fill_halo_regions(filled)                                   # the serial reference fill
+    ranks = []
+    for r in range(R):
+        arch = osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=r)
+        grid = osg.TripolarGrid(arch, size=size, halo=halo)
+        jstart, jend = grid.jrange
+        assert (jstart, jend) == (1 + 225 * r, 225 * (r + 1)) and grid.Ny == 225                     # SURVEY 8 a15
+        for name in osg._lib.ARRAY_NAMES:
+            assert torch.equal(getattr(grid, name), getattr(serial, name)[jstart - 1:jend + 2 * Hy]), (r, name)
+        fs = []
+        for (xl, yl, sg), g in zip(specs, globs):
+            loc = (osg.Face if xl else osg.Center, osg.Face if yl else osg.Center, osg.Center)
+            f = osg.Field(loc, grid)
+            assert osg.is_zipper(f.boundary_conditions.north) == (r == R - 1)
+            f.data.copy_(g[:, jstart - 1:jend + 2 * Hy])
+            f.data[:, :Hy] = 12345.0
+            f.data[:, Hy + 225:] = 12345.0                          # halo rows unknown before the fill
+            fs.append(f)
+        ranks.append((grid, fs))
+    mailbox = osg.LoopbackMailbox()
+    plans = [osg.halo_fill_plan(fs, exchange=mailbox.endpoint(r)) for r, (grid, fs) in enumerate(ranks)]
+    for plan in plans:
+        plan.begin()
+    for plan in plans:
+        plan.finish()
+    torch.cuda.synchronize()
+    for r, (grid, fs) in enumerate(ranks):
+        jstart, jend = grid.jrange
+        for f, ref in zip(fs, filled):
+            assert torch.equal(f.data, ref.data[:, jstart - 1:jend + 2 * Hy]), (r, f.loc)
