@@ -15,7 +15,7 @@
  *  - all array memory is DEVICE memory owned by the caller (Julia GC / torch); the library
  *    never allocates or frees device memory and keeps no reference past stream completion.
  *  - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
- *    re-entrant, graph-capturable, thread-safe for distinct streams.
+ *    re-entrant, graph-capturable (except the RCCL exchange, see tpg_halo_exchange_y), thread-safe for distinct streams.
  *  - array layout: column-major padded parent arrays, i fastest:
  *      2-D  A[i,j]   at  (i+Hx-1) + (Nx+2Hx) * (j+Hy-1)
  *      3-D  c[i,j,k] at  (i+Hx-1) + (Nx+2Hx) * ((j+Hy-1) + (Ny+2Hy) * (k+Hz-1))
@@ -185,7 +185,8 @@ int tpg_unpack_y_halo(void *const fields[], int nfields, const void *buffer, int
  * halo communication (src/distributed_tripolar_grid.jl:171 inject_halo_communication_boundary_conditions, :195
  * FieldBoundaryBuffers; MPI Isend/Irecv of one packed buffer per side [recalled]).  Here one call issues the whole
  * seam exchange of `nfields` fields of one geometry on `stream`: ONE ncclGroupStart/ncclGroupEnd of point-to-point
- * ncclSend/ncclRecv (RCCL over xGMI), no host wait, no collective, capturable in a HIP graph.
+ * ncclSend/ncclRecv (RCCL over xGMI), no host wait, no collective.  NOT to be captured into a HIP graph: a capture attempt of this
+ * call on the one-rank loop-back communicator did not complete (round 2); every other entry point is capture-safe.
  *   comm            ncclComm_t of the latitude-band chain (as void*): created by the host's RCCL binding, or by
  *                   tpg_comm_init_rank below (librccl is bound lazily with dlopen; TPG_ERR_RCCL if absent).
  *   rank, nranks    position in the chain: rank 0 is the southernmost band and has no south seam, rank nranks-1

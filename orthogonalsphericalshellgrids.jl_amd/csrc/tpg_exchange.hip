@@ -6,7 +6,7 @@
 // halos, all levels incl. the z halos) in both directions.  The reference's transport is MPI Isend/Irecv of one
 // packed buffer per side [recalled]; here it is ONE ncclGroupStart/ncclGroupEnd of point-to-point
 // ncclSend/ncclRecv on the caller's stream: no host wait, no collective (a y-slab chain only talks to its two
-// neighbours), capturable into a HIP graph.  Two message shapes:
+// neighbours).  (Not graph-capturable in practice: a capture attempt on the loop-back communicator hung, round 2.)  Two message shapes:
 //   packed    : tpg_pack_y_halo -> one message per seam direction ([field][level][Hy][sx], 9.58 MB per field at
 //               1/10 deg x 75 levels) -> tpg_unpack_y_halo;
 //   pack-free : the Hy seam rows of one (field, level) are already one contiguous window of the parent array

@@ -9,7 +9,7 @@ send/recv over xGMI.  No collective is involved: a y-slab chain only ever talks 
 Three transports, all bit-identical in what they deliver:
   * RcclComm (the production path): the C ABI's tpg_halo_exchange_y -- pack -> ONE ncclGroupStart/End of
     ncclSend/ncclRecv on the caller's stream -> unpack (or pack-free: the per-level contiguous seam windows sent
-    from / received into the fields directly).  No host wait, capturable in a HIP graph.  The communicator is
+    from / received into the fields directly).  No host wait.  The communicator is
     librccl's own (tpg_comm_init_rank); torch.distributed only ferries the 128-byte unique id.
   * torch_distributed_transport: `batch_isend_irecv` of the packed messages (backend "nccl" = RCCL, or "gloo" with
     host tensors): the Python convenience, and what the CPU/gloo tests of the host protocol run.

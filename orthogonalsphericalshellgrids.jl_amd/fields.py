@@ -267,11 +267,10 @@ class HaloFillPlan:
         """Capture `repeat` consecutive runs of this plan into one HIP graph (torch.cuda.CUDAGraph) and return
         it; `graph.replay()` then issues the whole sequence with a single launch -- the fills of a
         split-explicit sub-cycle are launch-bound, 2.7 us instead of 7 us per fill.
-        Distributed plans are capturable only on the C ABI's RCCL exchange (arch.rccl_comm: ncclSend/ncclRecv enqueue on
-        the captured stream); a torch.distributed or test transport cannot be captured."""
-        if any(seam is not None and (self._exchange is not None or getattr(arch, "rccl_comm", None) is None)
-               for _, _, seam, arch in self._steps):
-            raise ValueError("HaloFillPlan.graph: a seam exchange is capturable only through arch.rccl_comm (tpg_halo_exchange_y)")
+        Serial grids only: a seam exchange cannot be captured (torch.distributed cannot, and a capture attempt of the C ABI's RCCL
+        exchange on the one-rank loop-back communicator did not complete -- DESIGN.md 5)."""
+        if any(seam is not None for _, _, seam, _ in self._steps):
+            raise ValueError("HaloFillPlan.graph: plans with a distributed seam exchange cannot be captured")
         self()                                           # first-call work (occupancy queries, lazy module load) outside the capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
