@@ -684,7 +684,9 @@ int tpg_event_create(void** event)
 {
     if (!event) { tpg::set_error("null event pointer"); return TPG_ERR_INVALID_ARGUMENT; }
     hipEvent_t e;
-    int rc = tpg::hip_status(hipEventCreate(&e), "hipEventCreate");
+    // timing-only events: no system-scope fence when they complete (a default event attached to a launch turns the
+    // kernel's end-of-dispatch release into a system-scope one, which lands inside the measured interval)
+    int rc = tpg::hip_status(hipEventCreateWithFlags(&e, hipEventDisableSystemFence), "hipEventCreateWithFlags");
     *event = rc ? nullptr : e;
     return rc;
 }
