@@ -14,6 +14,7 @@ lib = _lib.lib()
 bad = 0
 for t in range(trials):
     Nx = 2 * int(rng.integers(1, 150)); Ny = int(rng.integers(1, 40)); Nz = int(rng.integers(1, 5))
+    if t % 40 == 7: Nx = int(rng.choice([1440, 3600, 8640, 4322])); Ny = int(rng.integers(10, 30))      # full-width rows of the BASELINE grids
     Hx = int(rng.integers(0, min(Nx, 7) + 1)); Hy = int(rng.integers(0, min(Ny, 10) + 1)); Hz = int(rng.integers(0, 3))
     nf = int(rng.integers(1, 6))
     dt, tdt, ft = ((np.float64, torch.float64, 1), (np.float32, torch.float32, 0))[t % 3 == 0]
