@@ -91,3 +91,31 @@ def test_halo_fill_plan_is_exported_and_validates_fields():
     assert callable(osg.halo_fill_plan) and osg.HaloFillPlan is not None
     plan = osg.halo_fill_plan([])
     assert plan() is None and plan.fields == []
+
+
+def test_loopback_mailbox_delivers_in_order(osg):
+    """two-phase transport of the emulated-rank tests: every posted message reaches the peer's receive buffer, in posting order"""
+    import torch
+    from orthogonalsphericalshellgrids.jl_amd.distributed import NORTH, SOUTH
+    box = osg.LoopbackMailbox()
+    R = 3
+    plans = [osg.exchange_plan(r, R) for r in range(R)]
+    assert [[(m.side, m.peer) for m in p] for p in plans] == [[(NORTH, 1)], [(NORTH, 2), (SOUTH, 0)], [(SOUTH, 1)]]
+    handles = []
+    for batch in (0, 1):                                              # two batches per fill (more than TPG_MAX_FIELDS fields)
+        for r, plan in enumerate(plans):
+            send = {m.side: torch.full((4,), 100.0 * batch + 10 * r + m.side) for m in plan}
+            recv = {m.side: torch.zeros(4) for m in plan}
+            handles.append((r, batch, box.endpoint(r).post(plan, send, recv)))
+    for r, batch, h in handles:
+        box.endpoint(r).wait(h)
+        plan, recv = h
+        for m in plan:                                                # what the peer sent towards us: its side facing us
+            want = 100.0 * batch + 10 * m.peer + (SOUTH if m.side == NORTH else NORTH)
+            assert bool((recv[m.side] == want).all()), (r, batch, m)
+    assert all(not q for q in box.box.values())
+
+
+def test_rccl_comm_rejects_a_malformed_unique_id(osg):
+    with pytest.raises(ValueError):
+        osg.RcclComm.create(b"short", 0, 1)
