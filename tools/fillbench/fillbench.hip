@@ -581,6 +581,19 @@ int main(int argc, char** argv)
         auto r = run3([&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(k_per0, grid0, dim3(256), 0, 0, a, b, 0, g_ft, nrows); }, rounds);
         report("per0 (product form)", r, pbytes);
     }
+    if (exp == "seq") {
+        // what the fold leaves behind for the periodic pass that follows it in a fill: plain stores vs write-through stores
+        dim3 grid((NZ * NCH + 255) / 256, NF);
+        dim3 gridp((unsigned)((nrows * 2 + 255) / 256), NF);
+        for (int it = 0; it < rounds + 2; ++it)
+            for (int v = 0; v < 2; ++v) {
+                hipLaunchKernelGGL(k_flush_clean, dim3(8192), dim3(256), 0, 0, g_flush, FLUSH_N, g_flush);
+                if (v == 0) hipLaunchKernelGGL((k_cols<false, 1, 0, false>), grid, dim3(256), 0, 0, g_ft, NZ, (unsigned long long*)nullptr);
+                else        hipLaunchKernelGGL((k_cols<false, 1, 2, false>), grid, dim3(256), 0, 0, g_ft, NZ, (unsigned long long*)nullptr);
+                hipLaunchKernelGGL(k_per0, gridp, dim3(256), 0, 0, g_ft, nrows);
+            }
+        CHECK(hipDeviceSynchronize());
+    }
     if (want("timeline")) {
         for (int mode = 0; mode < 3; ++mode) timeline("fold", false, mode);
         timeline("copy", true, 1);

@@ -15,7 +15,7 @@ fi
 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o fb -- "$BIN" "$EXP" "$ROUNDS" > "$OUT/log.txt" 2>&1
 echo "rocprofv3 rc=$?"
 cat "$OUT/log.txt"
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "$EXP" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
 rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
@@ -24,7 +24,7 @@ prev = ""
 for r in rows:
     n = r["Kernel_Name"]
     if not ("k_flush" in n or "k_init" in n or "fillBuffer" in n):
-        mode = "cold-dirty" if "k_flush_dirty" in prev else ("cold-clean" if "k_flush_clean" in prev else "warm")
+        mode = "cold-dirty" if "k_flush_dirty" in prev else ("cold-clean" if "k_flush_clean" in prev else ("after " + prev.split("(")[0][-28:] if sys.argv[2] == "seq" else "warm"))
         acc.setdefault(n, collections.OrderedDict()).setdefault(mode, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     prev = n
 print("device durations (rocprofv3 kernel trace) by kernel and by what ran just before it; first 2 launches per state dropped:")
