@@ -1,27 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- TripolarGrid metric precompute + zipper halo fill at 1/10 deg x 75 levels on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch of synthetic input, resident in HBM:
   (1) tpg_build_grid : coordinates + 12 staggered metrics of this rank's latitude band
                        (N = 1: the whole 3600 x 1800 globe, Float64, halo 4) -> 20 padded arrays;
-  (2) fill_halo_regions! of the 4 synthetic 3600 x 1800 x 75 Float64 fields c(CC,+1) u(FC,-1)
-      v(CF,-1) zeta(FF,+1): zipper fold (ONE batched launch; north rank only) + periodic x
-      (+ for N > 1 the y-seam exchange of Hy rows with the neighbour ranks: tpg_halo_exchange_y, RCCL send/recv).
-N > 1 is WEAK scaling: every rank keeps a 3600 x 1800 x 75 band of a 3600 x (1800 N) x 75 global
-tripolar grid (latitude bands, src/distributed_tripolar_grid.jl); no data-path collective.  For N > 1
-the step is ordered zipper -> periodic x -> [seam exchange on a side stream || grid build]: the
-exchange only needs the filled fields, the build only writes the grid arrays.
+  (2) fill_halo_regions! of the 4 synthetic Float64 fields c(CC,+1) u(FC,-1) v(CF,-1) zeta(FF,+1), 75 levels, through the
+      product's own entry point -- N = 1: tpg_fill_halo_regions (ONE merged launch: zipper fold + periodic x);
+      N > 1: tpg_fill_halo_regions_distributed (zipper on the north rank -> periodic x -> RCCL y-seam exchange of Hy rows).
 
-Exactly W untimed warm-up steps, then exactly K timed steps.  The auxiliary measurements the line also carries
-(zipper launch duration from cold / warm caches, the same-shape copy ceiling, the config-5 `fill_step`) run BEFORE
-the warm-up steps; they are separate measurements, not steps, and they leave the GPU at its steady clocks.
+N > 1, default `--scaling strong` = BASELINE config 4: the SAME 3600 x 1800 x 75 globe split into N latitude bands of 1800/N
+rows (N = 8: ny = 225, rank 7 owns the zipper; src/distributed_tripolar_grid.jl:36-49,75,143-147); no data-path collective,
+point-to-point seams only.  `--scaling weak` keeps 1800 rows per rank of a 3600 x (1800 N) x 75 globe (not a BASELINE config).
+For N > 1 the halo fill (local fill + seam exchange) runs on a side stream beside the grid build on the main stream: the
+two touch disjoint memory.  Before the warm-up one fill runs under a host-side deadline: a stalled exchange ends the job
+with a one-line JSON diagnostic on stderr and a non-zero exit instead of a silent hang.
 
-value = horizontal grid cells of all ranks / step time (max over ranks).  `roofline` is the zipper
-kernel (the HBM-bound kernel BASELINE.json's north_star sets the 70 % target on); the precompute
-kernel, which dominates the step time but is FP64-transcendental bound, is reported beside it.
+Exactly W untimed warm-up steps, then exactly K timed steps.  The auxiliary measurements the line also carries (fold-only
+launches by cache state, the same-shape copy ceiling, Float32 figures, config 2, config 5) run BEFORE the warm-up; the
+fold-only pass behind `roofline_fold` and the per-phase breakdown run AFTER the timed steps.  None of them is a step.
+
+value = horizontal grid cells of all ranks / step time (max over ranks).  `roofline` is the halo-fill kernel the step launches
+(k_fill_merged: the zipper halo fill as the product issues it, HBM-bound); `roofline_fold` is the fold alone (k_zipper_cols, the
+kernel BASELINE.json's north_star puts the 70 % target on); the precompute kernel, which dominates the step time but is
+FP64-issue bound, is `roofline_precompute`.
 """
 import argparse
 import ctypes as C
@@ -30,6 +34,7 @@ import json
 import os
 import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,6 +45,7 @@ SPECS = [("c", 0, 0, 1), ("u", 1, 0, -1), ("v", 0, 1, -1), ("zeta", 1, 1, 1)]   
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (datasheet)
 LIB = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "libtripolar_hip.so")
+KERNEL_SOURCE = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "csrc", "tpg_zipper_kernels.hpp")
 
 
 def zipper_algorithmic_bytes(nx, nz, hy, specs=SPECS, s=8):
@@ -51,6 +57,11 @@ def zipper_algorithmic_bytes(nx, nz, hy, specs=SPECS, s=8):
             b += (nx // 2) * nz * 2 * s
         per_field[name] = b
     return per_field
+
+
+def periodic_algorithmic_bytes(ny, nz, h, nfields, s=8):
+    """Oceananigans' periodic west/east fill: 2 Hx elements read + 2 Hx written per row, every row and level of the parent"""
+    return nfields * (ny + 2 * h) * (nz + 2 * h) * 2 * h * 2 * s
 
 
 def cpu_share():
@@ -118,28 +129,64 @@ def cpu_baseline():
     }
 
 
+class Watchdog:
+    """Host-side deadline for the first contact with the other ranks (communicator bring-up, first seam exchange).  A
+    mis-paired or stalled RCCL group blocks either the host (inside ncclGroupEnd) or the device (the stream never drains);
+    a timer thread covers both: on expiry it prints ONE JSON line (rank, peers, transport, phase) to stderr and leaves with
+    os._exit(3) -- no re-exec, no retry in this process: a fresh child is the only retry."""
+
+    def __init__(self, seconds, info):
+        self.seconds, self.info, self.phase, self._timer = seconds, dict(info), "idle", None
+
+    def _fire(self):
+        d = dict(self.info, event="bench_deadline_expired", phase=self.phase, deadline_s=self.seconds)
+        print(json.dumps(d), file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def arm(self, phase):
+        self.disarm()
+        self.phase = phase
+        self._timer = threading.Timer(self.seconds, self._fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def set_phase(self, phase):
+        self.phase = phase
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+        self.phase = "idle"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = BASELINE config 4 (the 3600x1800x75 globe in N bands of 1800/N rows; default); weak = 1800 rows per rank")
+    ap.add_argument("--deadline", type=float, default=float(os.environ.get("TPG_BENCH_DEADLINE_S", "120")),
+                    help="seconds allowed for communicator bring-up and for the first seam exchange (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fill-step", action="store_true", help="skip the config-5 (1/24 deg x 100 levels) fill_step measurement")
-    ap.add_argument("--no-aux", action="store_true", help="skip the cold/warm zipper and copy-ceiling measurements")
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary measurements (cache states, copy ceiling, Float32, config 2, geometry)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(os.path.join(ROOT, "tools", "libtripolar_hip_test.so"))):
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:            # fresh checkout: build once (hipcc, gcc)
             import __graft_entry__
             __graft_entry__.build()
-        else:                                                       # the Makefile renames the finished library into place
-            while not os.path.exists(LIB):
+        else:                                                       # the Makefile renames the finished libraries into place
+            while not (os.path.exists(LIB) and os.path.exists(os.path.join(ROOT, "tools", "libtripolar_hip_test.so"))):
                 time.sleep(0.5)
     import orthogonalsphericalshellgrids.jl_amd as osg
     from orthogonalsphericalshellgrids.jl_amd import _lib
     from orthogonalsphericalshellgrids.jl_amd.distributed import PendingExchange
+    from tools import testlib                                       # synthetic fill + copy probe only; every step call is the product library's
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -150,64 +197,77 @@ def main():
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    strong = world > 1 and args.scaling == "strong"
+    if strong and NY % world:
+        # the remainder rule of Oceananigans' local_size for Ny % R != 0 is unpinned: config 4 divides evenly
+        raise SystemExit(f"--scaling strong needs {NY} % N == 0 (N = {world}); use N in 1,2,3,4,5,6,8,... or --scaling weak")
     rehearse = os.environ.get("TPG_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    peers = {"south": rank - 1 if rank > 0 else None, "north": rank + 1 if rank < world - 1 else None}
+    dog = Watchdog(args.deadline, {"rank": rank, "world": world, "peers": peers, "device": local_rank})
     # Rehearsal mode for a 1-GPU box (never used by the driver): TPG_BENCH_REHEARSE=1 runs the N-rank
     # code path with every rank on cuda:0 and the seam messages staged through host memory over gloo
     # (RCCL refuses two ranks on one device).  Timings of such a run are meaningless.
-    comm = None
+    comm, comm_error = None, None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            dog.info["transport"] = "librccl via tpg_comm_init_rank"
+            dog.arm("torch.distributed init_process_group(nccl)")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            # the exchange itself is librccl through the C ABI (tpg_halo_exchange_y); should its communicator fail to come up
-            # on ANY rank, every rank falls back to torch.distributed's batch_isend_irecv (also RCCL) and the line says so
+            # The exchange itself is librccl through the C ABI (tpg_halo_exchange_y).  RcclComm.from_torch first lets every rank report
+            # whether it can bind librccl and agrees on that BEFORE the collective ncclCommInitRank; should the communicator still fail
+            # to come up on any rank, every rank falls back to torch.distributed's batch_isend_irecv (also RCCL) and the line says so.
+            dog.set_phase("RcclComm.from_torch (readiness agreement + ncclCommInitRank)")
             try:
                 comm = osg.RcclComm.from_torch()
-                comm_error = None
             except Exception as e:                                  # noqa: BLE001
                 comm, comm_error = None, f"{type(e).__name__}: {e}"
             ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0 and comm is not None:
                 comm.destroy(); comm = None
+            dog.disarm()
             if comm is None:
+                dog.info["transport"] = "torch.distributed batch_isend_irecv"
                 print(f"[bench rank {rank}] tpg_comm_init_rank unavailable ({comm_error}); seam exchange over torch.distributed", file=sys.stderr)
 
-    lib = _lib.lib()
-    gsize = (NX, NY * world, NZ)                                   # weak scaling: 1800 rows per rank
+    lib, tlib = _lib.lib(), testlib.lib()
+    ny = NY // world if strong else NY                             # rows of this rank's band
+    gsize = (NX, NY, NZ) if (strong or world == 1) else (NX, NY * world, NZ)
     if world > 1:
         arch = osg.Distributed(osg.GPU(0 if rehearse else local_rank), osg.Partition(y=world), local_rank=rank, rccl_comm=comm)
         jstart, jend = osg.local_row_range(gsize[1], arch)
+        assert jend - jstart + 1 == ny, (jstart, jend, ny)
     else:
         arch, jstart, jend = osg.GPU(local_rank), 1, NY
     north_rank = rank == world - 1
 
     # ---- resident inputs / outputs -------------------------------------------------------------
     p = _lib.TpgParams(gsize[0], gsize[1], gsize[2], H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F64, jstart, jend, 0)
-    rows = jend - jstart + 1 + 2 * H
+    rows = ny + 2 * H
     out = [torch.empty((rows, NX + 2 * H), dtype=torch.float64, device=dev) for _ in _lib.ARRAY_NAMES]
     out_ptrs = _lib.ptr_table(out)
     ws = torch.empty(int(lib.tpg_build_grid_workspace_bytes(C.byref(p))), dtype=torch.uint8, device=dev)
-    shape = (NZ + 2 * H, NY + 2 * H, NX + 2 * H)
+    shape = (NZ + 2 * H, ny + 2 * H, NX + 2 * H)
     fields = []
     for fid, _ in enumerate(SPECS):
         f = torch.empty(shape, dtype=torch.float64, device=dev)
-        _lib.check(lib.tpg_fill_synthetic(f.data_ptr(), 0x5EED + fid + 16 * rank, 12345.0, NX, NY, NZ, H, H, H, _lib.TPG_F64, None))
+        testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0x5EED + fid + 16 * rank, 12345.0, NX, ny, NZ, H, H, H, _lib.TPG_F64, None))
         fields.append(f)
     fptrs = _lib.ptr_table(fields)
     n = len(SPECS)
     xl = (C.c_int8 * n)(*[s[1] for s in SPECS]); yl = (C.c_int8 * n)(*[s[2] for s in SPECS]); sg = (C.c_int32 * n)(*[s[3] for s in SPECS])
-    geom = (NX, NY, NZ, H, H, H)
+    geom = (NX, ny, NZ, H, H, H)
 
     class BandField:                                                # what the seam exchange needs of a Field
         def __init__(self, data):
-            self.data, self.Nx, self.Ny, self.Nz, self.Hx, self.Hy, self.Hz = data, NX, NY, NZ, H, H, H
+            self.data, self.Nx, self.Ny, self.Nz, self.Hx, self.Hy, self.Hz = data, NX, ny, NZ, H, H, H
     band_fields = [BandField(f) for f in fields]
 
     stream = _lib.current_stream_ptr(dev)
@@ -222,8 +282,14 @@ def main():
             for k in recv:
                 recv[k].copy_(hr[k])
 
-    def exchange():
-        PendingExchange(band_fields, arch, transport).begin().finish()
+    # seam message buffers: owned here for the C call (RCCL path), by the PendingExchange otherwise
+    seam, seam_ptr = None, [None] * 4
+    if world > 1 and comm is not None:
+        nelem = int(lib.tpg_y_halo_buffer_elems(n, NX, NZ, H, H, H))
+        seam = {k: torch.empty(nelem, dtype=torch.float64, device=dev) for k in ("ss", "sn", "rs", "rn")}
+        seam_ptr = [seam["ss"].data_ptr() if rank > 0 else None, seam["sn"].data_ptr() if not north_rank else None,
+                    seam["rs"].data_ptr() if rank > 0 else None, seam["rn"].data_ptr() if not north_rank else None]
+    pending = PendingExchange(band_fields, arch, transport) if (world > 1 and comm is None) else None
 
     def hip_event():
         e = C.c_void_p()
@@ -235,61 +301,57 @@ def main():
         _lib.check(lib.tpg_event_elapsed_ms(e0, e1, C.byref(ms)))
         return ms.value
 
-    def zipper(zev):
-        if not north_rank:
-            return
-        if zev is not None:         # the kernel's own start/stop device timestamps (hipExtLaunchKernelGGL)
-            _lib.check(lib.tpg_zipper_fill_timed(fptrs, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F64, stream, zev[0], zev[1]))
+    def local_fill(kev=None):
+        """fill_halo_regions! without the seams: zipper (north rank) -> periodic x; kev = the first kernel's own start/stop events"""
+        s_ = _lib.current_stream_ptr(dev)
+        if kev is not None:
+            _lib.check(lib.tpg_fill_halo_regions_timed(fptrs, n, xl, yl, sg, *geom, 1 if north_rank else 0, _lib.TPG_F64, s_, kev[0], kev[1]))
         else:
-            _lib.check(lib.tpg_zipper_fill(fptrs, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F64, stream))
+            _lib.check(lib.tpg_fill_halo_regions(fptrs, n, xl, yl, sg, *geom, 1 if north_rank else 0, _lib.TPG_F64, s_))
 
-    def step_serial(marks=None, zev=None):
-        """N = 1: build -> zipper -> periodic x, one stream"""
-        if marks is not None: marks[0].record()
+    def exchange_only():
+        s_ = _lib.current_stream_ptr(dev)
+        if comm is not None:
+            _lib.check(lib.tpg_halo_exchange_y(comm.handle, rank, world, fptrs, n, *seam_ptr, *geom, _lib.TPG_F64, s_))
+        else:
+            pending.begin().finish()
+
+    def distributed_fill():
+        """the whole fill_halo_regions! of a DistributedTripolarGrid: ONE C call on the RCCL path"""
+        if comm is not None:
+            _lib.check(lib.tpg_fill_halo_regions_distributed(comm.handle, rank, world, fptrs, n, xl, yl, sg, *seam_ptr, *geom, _lib.TPG_F64,
+                                                             _lib.current_stream_ptr(dev)))
+        else:
+            local_fill()
+            exchange_only()
+
+    def build():
         _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
-        if marks is not None: marks[1].record()
-        zipper(zev)
-        if marks is not None: marks[2].record()
-        _lib.check(lib.tpg_periodic_x_fill(fptrs, n, *geom, _lib.TPG_F64, stream))
-        if marks is not None: marks[3].record()
+
+    def step_serial(kev=None):
+        """N = 1: build -> fill_halo_regions! (one merged launch), one stream"""
+        build()
+        local_fill(kev)
 
     main_stream = torch.cuda.current_stream(dev)
     side_stream = torch.cuda.Stream(dev) if world > 1 else None
-
-    def step_overlapped(marks=None, zev=None):
-        """N > 1: the halo fill's seam exchange (pack -> RCCL send/recv -> unpack, side stream) runs
-        concurrently with the grid build (main stream); the two touch disjoint memory.  The tile kernel of the build is
-        ~15 000 short blocks, so RCCL's send/recv workgroups simply take a few wave slots from it.
-        marks: [0] start, [1] after the zipper, [2] after periodic x, [3] end of the build (main stream),
-               [4] / [5] exchange start / end (side stream)"""
-        if marks is not None: marks[0].record()
-        zipper(zev)
-        if marks is not None: marks[1].record()
-        _lib.check(lib.tpg_periodic_x_fill(fptrs, n, *geom, _lib.TPG_F64, stream))
-        if marks is not None: marks[2].record()
-        side_stream.wait_stream(main_stream)
-        with torch.cuda.stream(side_stream):
-            if marks is not None: marks[4].record()
-            exchange()
-            if marks is not None: marks[5].record()
-        _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
-        if marks is not None: marks[3].record()
-        main_stream.wait_stream(side_stream)
-
-    def step_serial_exchange(marks=None, zev=None):
-        """N > 1 without overlap (TPG_BENCH_OVERLAP=0): same work, one stream; marks [4] / [5] bracket the exchange"""
-        if marks is not None: marks[0].record()
-        zipper(zev)
-        if marks is not None: marks[1].record()
-        _lib.check(lib.tpg_periodic_x_fill(fptrs, n, *geom, _lib.TPG_F64, stream))
-        if marks is not None: marks[2].record(); marks[4].record()
-        exchange()
-        if marks is not None: marks[5].record()
-        _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
-        if marks is not None: marks[3].record()
-
     overlap = world > 1 and os.environ.get("TPG_BENCH_OVERLAP", "1") != "0"
-    step = step_overlapped if overlap else (step_serial_exchange if world > 1 else step_serial)
+
+    def step_distributed(kev=None):
+        """N > 1: the halo fill (zipper on the north rank -> periodic x -> seam exchange) on a side stream beside the grid
+        build on the main stream; the two touch disjoint memory.  The tile kernel of the build is thousands of short blocks,
+        so RCCL's send/recv workgroups simply take a few wave slots from it.  TPG_BENCH_OVERLAP=0: same work on one stream."""
+        if overlap:
+            side_stream.wait_stream(main_stream)
+            with torch.cuda.stream(side_stream):
+                distributed_fill()
+            build()
+            main_stream.wait_stream(side_stream)
+        else:
+            distributed_fill()
+            build()
+
+    step = step_distributed if world > 1 else step_serial
 
     def sync():
         torch.cuda.synchronize()
@@ -297,183 +359,187 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- auxiliary measurements (not steps): zipper launch duration by cache state, copy ceiling, config-5 fills ----------
+    # ---- N > 1: first contact with the neighbours under a deadline ---------------------------------------------------------
+    if world > 1:
+        dog.info.update(geometry=list(geom), seam_message_MB=4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8 / 1e6)
+        if os.environ.get("TPG_BENCH_TEST_STALL_RANK") == str(rank):      # tests/test_gpu_bench_contract.py: a rank that never posts its half
+            time.sleep(3 * args.deadline)
+            os._exit(4)
+        dog.arm("first seam exchange: enqueue (host inside ncclGroupEnd / batch_isend_irecv)")
+        distributed_fill()
+        dog.set_phase("first seam exchange: device (stream not drained: a peer never posted its half of the group?)")
+        torch.cuda.synchronize()
+        dog.set_phase("barrier after the first seam exchange")
+        dist.barrier()
+        dog.disarm()
+
+    # ---- auxiliary measurements (not steps) ----------------------------------------------------------------------------------
     aux = {}
     if world == 1 and not args.no_aux:
-        flush = torch.zeros(1 << 27, dtype=torch.float64, device=dev)          # 1 GiB: evicts L2 + Infinity Cache
-        e0, e1 = hip_event(), hip_event()
-        acc = {"cold_dirty": [], "cold_clean": [], "warm": [], "copy_cold_clean": []}
-        for it in range(22):
-            flush.add_(1.0)                                                     # predecessor leaves the caches full of dirty lines
-            zipper((e0, e1)); acc["cold_dirty"].append(elapsed_ms(e0, e1))
-            flush.sum()                                                         # ... full of clean lines
-            zipper((e0, e1)); acc["cold_clean"].append(elapsed_ms(e0, e1))
-            zipper((e0, e1)); acc["warm"].append(elapsed_ms(e0, e1))            # back-to-back relaunch (Infinity-Cache resident)
-            flush.sum()
-            _lib.check(lib.tpg_zipper_copy_probe(fptrs, n, yl, *geom, _lib.TPG_F64, stream, e0, e1))
-            acc["copy_cold_clean"].append(elapsed_ms(e0, e1))
-        med = {k: statistics.median(v[2:]) for k, v in acc.items()}             # first 2 rounds dropped
-        aux = {"zipper_cold_ms": med["cold_clean"], "zipper_cold_dirty_ms": med["cold_dirty"], "zipper_warm_ms": med["warm"],
-               "zipper_copy_ceiling_ms": med["copy_cold_clean"],
-               "zipper_states_note": "kernel start/stop events, median of 20: after a 1 GiB read-only pass (cold), after a 1 GiB "
-                                     "in-place write (cold_dirty), back-to-back relaunch (warm); copy_ceiling = the same launch "
-                                     "shape and bytes as a pure copy (tpg_zipper_copy_probe), cold"}
-        lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
-        del flush
-        for fid, f in enumerate(fields):                                        # the copy probe left unfolded halos behind
-            _lib.check(lib.tpg_fill_synthetic(f.data_ptr(), 0x5EED + fid, 12345.0, NX, NY, NZ, H, H, H, _lib.TPG_F64, None))
-        # BASELINE config 2: the 1/4 degree (1440 x 720) Float64 metric precompute alone, 20 back-to-back builds
-        p2 = _lib.TpgParams(1440, 720, 1, H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F64, 1, 720, 0)
-        out2 = [torch.empty((720 + 2 * H, 1440 + 2 * H), dtype=torch.float64, device=dev) for _ in _lib.ARRAY_NAMES]
-        ptr2 = _lib.ptr_table(out2)
-        ws2 = torch.empty(int(lib.tpg_build_grid_workspace_bytes(C.byref(p2))), dtype=torch.uint8, device=dev)
-        for _ in range(3):
-            _lib.check(lib.tpg_build_grid(C.byref(p2), ptr2, ws2.data_ptr(), ws2.numel(), stream))
-        b0, b1 = ev(), ev()
-        b0.record()
-        for _ in range(20):
-            _lib.check(lib.tpg_build_grid(C.byref(p2), ptr2, ws2.data_ptr(), ws2.numel(), stream))
-        b1.record(); torch.cuda.synchronize()
-        us2 = b0.elapsed_time(b1) / 20 * 1e3
-        aux["config2_quarter_degree_build"] = {"size": [1440, 720, 1], "us_per_build": us2, "cells_per_s": 1440 * 720 / (us2 * 1e-6),
-                                               "store_GBps": 160.0 * 1448 * 728 / (us2 * 1e-6) / 1e9}
-        del out2, ws2
-        # SURVEY 8(f-4) geometry utilities at the bench's own size, on the grid arrays the warm-up build just has to produce
-        _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
-        arr = dict(zip(_lib.ARRAY_NAMES, out))
-        angle = torch.empty((NY, NX), dtype=torch.float64, device=dev)
-        uo, vo = torch.zeros_like(fields[0]), torch.zeros_like(fields[0])
-
-        def timed_us(fn, reps):
-            fn(); torch.cuda.synchronize()
-            t0_, t1_ = ev(), ev()
-            t0_.record()
-            for _ in range(reps):
-                fn()
-            t1_.record(); torch.cuda.synchronize()
-            return t0_.elapsed_time(t1_) / reps * 1e3
-
-        t_ang = timed_us(lambda: _lib.check(lib.tpg_nonorthogonality_angle(arr["lambda_ff"].data_ptr(), arr["phi_ff"].data_ptr(), None,
-                                                                           angle.data_ptr(), NX, NY, H, H, _lib.TPG_F64, stream)), 20)
-        t_rot = timed_us(lambda: _lib.check(lib.tpg_convert_frame(arr["phi_cf"].data_ptr(), arr["phi_fc"].data_ptr(), arr["dy_cc"].data_ptr(),
-                                                                  arr["dx_cc"].data_ptr(), fields[0].data_ptr(), fields[1].data_ptr(),
-                                                                  uo.data_ptr(), vo.data_ptr(), 0, *geom, _lib.TPG_F64, stream)), 5)
-        rot_bytes = 4 * NX * NY * NZ * 8                                        # 2 fields read + 2 written, interior cells
-        aux["geometry_utilities"] = {
-            "nonorthogonality_angle_us": t_ang, "nonorthogonality_max_abs_deg_unmasked": float(angle.abs().max()),
-            "convert_frame_us": t_rot, "convert_frame_algorithmic_bytes": rot_bytes,
-            "convert_frame_frac_of_hbm_peak": rot_bytes / (t_rot * 1e-6) / 1e9 / HBM_PEAK_GBPS}
-        del angle, uo, vo
+        aux = auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, sg, geom, p, out, out_ptrs, ws, hip_event, elapsed_ms)
     fill_step = None
     if world == 1 and not args.no_fill_step:
         torch.cuda.synchronize()
         torch.cuda.empty_cache()                                    # hand the auxiliary buffers back before sizing 162 GB of fields
-        fill_step = fill_step_config5(torch, osg, _lib, dev)
+        fill_step = fill_step_config5(torch, osg, _lib, tlib, dev)
 
     # ---- W warm-up steps, K timed steps ------------------------------------------------------------------------------------
     sync()
     for _ in range(args.warmup):
         step()
     sync()
-    # Timed region: K steps; the only instrumentation inside it is the zipper kernel's own start/stop
-    # timestamps (they ride on its dispatch packet).  Stream-marker events between the phases cost
-    # ~10 us of queue bubbles each (kernel trace: 0.3 us between kernels of one call, 9-11 us across a
-    # marker), so the per-phase breakdown is taken in a second, untimed pass of the same K steps.
-    zevs = [(hip_event(), hip_event()) for _ in range(args.steps)] if north_rank else [None] * args.steps
+    # Timed region: K steps; the only instrumentation inside it is the fill kernel's own start/stop timestamps (they ride on its
+    # dispatch packet; N = 1).  Stream-marker events between the phases cost ~10 us of queue bubbles each, so the per-phase
+    # breakdown is taken in a second, untimed pass of the same K steps.
+    kevs = [(hip_event(), hip_event()) for _ in range(args.steps)] if world == 1 else [None] * args.steps
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(None, zevs[k])
+        step(kevs[k])
     sync()
     elapsed = time.perf_counter() - t0
-    marks = [[ev() for _ in range(6)] for _ in range(args.steps)]
-    for k in range(args.steps):
-        step(marks[k], None)
-    sync()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=None if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- untimed instrumented pass: phase brackets (and, N > 1, the north rank's fill-kernel duration) -----------------------
+    def reduce_max(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=None if rehearse else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    marks = [[ev() for _ in range(6)] for _ in range(args.steps)]
+    kev2 = [(hip_event(), hip_event()) for _ in range(args.steps)] if (world > 1 and north_rank) else None
+    for k in range(args.steps):
+        m = marks[k]
+        if world == 1:
+            m[0].record(); build(); m[1].record(); local_fill(); m[2].record()
+        elif overlap:
+            side_stream.wait_stream(main_stream)
+            with torch.cuda.stream(side_stream):
+                m[3].record(); local_fill(kev2[k] if kev2 else None); m[4].record(); exchange_only(); m[5].record()
+            m[0].record(); build(); m[1].record()
+            main_stream.wait_stream(side_stream)
+        else:
+            m[3].record(); local_fill(kev2[k] if kev2 else None); m[4].record(); exchange_only(); m[5].record()
+            m[0].record(); build(); m[1].record()
+    sync()
     avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)      # ms
-    t_exchange = None
-    if world > 1:      # marks: [start, zipper, periodic, build end, exchange start, exchange end]
-        t_zip_bracket, t_periodic = avg(0, 1), avg(1, 2)
-        t_exchange = avg(4, 5)                                          # pack + send/recv + unpack
-        t_build = avg(2, 3) if overlap else avg(5, 3)                   # serial order: the build starts after the exchange
-        te = torch.tensor([t_exchange], dtype=torch.float64, device=None if rehearse else dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)                       # the slowest rank's seams
-        t_exchange = float(te.item())
-    else:
-        t_build, t_zip_bracket, t_periodic = avg(0, 1), avg(1, 2), avg(2, 3)
-    t_zip = t_zip_bracket
-    if north_rank:
-        tot = 0.0
-        for e0, e1 in zevs:
-            tot += elapsed_ms(e0, e1)
+    t_build = avg(0, 1)
+    if world == 1:
+        t_fill_bracket, t_exchange, t_fillx = avg(1, 2), None, None
+        t_fill_kernel = sum(elapsed_ms(e0, e1) for e0, e1 in kevs) / len(kevs)      # the merged kernel's own duration, timed steps
+        for e0, e1 in kevs:
             lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
-        t_zip = tot / len(zevs)                                     # kernel duration, not the bracket
-    if world > 1:
-        # the zipper runs on the north (last) rank only: ship its launch time to rank 0 for the report
-        tz = torch.tensor([t_zip], dtype=torch.float64, device=None if rehearse else dev)
-        dist.broadcast(tz, src=world - 1)
-        t_zip = float(tz.item())
+    else:
+        t_fill_bracket, t_exchange, t_fillx = avg(3, 4), avg(4, 5), avg(3, 5)
+        t_fill_kernel = 0.0
+        if kev2:
+            t_fill_kernel = sum(elapsed_ms(e0, e1) for e0, e1 in kev2) / len(kev2)
+            for e0, e1 in kev2:
+                lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
+        t_build_max, t_exchange, t_fillx = reduce_max(t_build), reduce_max(t_exchange), reduce_max(t_fillx)
+        t_fill_kernel = reduce_max(t_fill_kernel)                                    # only the north rank has one
+        t_build = t_build_max
+
+    # ---- N = 1: fold-only pass, K old-style steps (build -> tpg_zipper_fill [k_zipper_cols] -> tpg_periodic_x_fill) -------
+    fold = None
+    if world == 1:
+        fevs = [(hip_event(), hip_event()) for _ in range(args.steps)]
+        for k in range(args.steps):
+            build()
+            _lib.check(lib.tpg_zipper_fill_timed(fptrs, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F64, stream, fevs[k][0], fevs[k][1]))
+            _lib.check(lib.tpg_periodic_x_fill(fptrs, n, *geom, _lib.TPG_F64, stream))
+        torch.cuda.synchronize()
+        fold = sum(elapsed_ms(e0, e1) for e0, e1 in fevs) / len(fevs)
+        for e0, e1 in fevs:
+            lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        cells = NX * NY * world
-        zb = zipper_algorithmic_bytes(NX, NZ, H)
-        zbytes = sum(zb.values())
-        band_cells = (jend - jstart + 1 + 2 * H) * (NX + 2 * H)
-        per_rows = (NY + 2 * H) * (NZ + 2 * H) * n
+        cells = gsize[0] * gsize[1]
+        zbytes = sum(zipper_algorithmic_bytes(NX, NZ, H).values())
+        pbytes = periodic_algorithmic_bytes(ny, NZ, H, n)
+        fill_bytes = zbytes + pbytes                                # north rank / N = 1
+        band_cells = (ny + 2 * H) * (NX + 2 * H)
         line = {
             "metric": "grid-cells/s metric precompute + zipper halo-fill GB/s, 1/10°×75z",
             "value": cells / (elapsed / args.steps), "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "TripolarGrid 1/10deg metric precompute (3600x1800 per rank, Float64, halo 4) + "
-                                   "fill_halo_regions! of 4 fields c/u/v/zeta (3600x1800x75 per rank): zipper + periodic-x"
-                                   + (" + RCCL y-seam exchange" if world > 1 else ""),
-                       "global_size": list(gsize), "local_size": [NX, NY, NZ], "halo": [H, H, H], "fields": [s[0] for s in SPECS],
-                       "parallelism": f"latitude-bands x{world}"},
-            "precompute_cells_per_s": NX * NY / (t_build * 1e-3),
-            "precompute_ms": t_build, "zipper_ms": t_zip, "zipper_bracket_ms": t_zip_bracket, "periodic_x_ms": t_periodic,
-            "overlap": "seam exchange on a side stream, concurrent with the grid build" if overlap else None,
-            "exchange_ms": t_exchange,                                  # max over ranks; per seam direction: 4 fields x 9.58 MB
-            "exchange_transport": None if world == 1 else ("gloo, host-staged (rehearsal: timings meaningless)" if rehearse
-                                                           else ("tpg_halo_exchange_y: librccl ncclSend/ncclRecv group, packed messages" if comm is not None
-                                                                 else "torch.distributed batch_isend_irecv (nccl = RCCL), packed messages [fallback]")),
-            "seam_GBps_per_direction": (4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8 / (t_exchange * 1e-3) / 1e9) if t_exchange else None,
-            "zipper_GBps": zbytes / (t_zip * 1e-3) / 1e9,
-            # the periodic pass is bound by the 128-B lines it must touch, not by the bytes it needs from them:
-            # per row pair 3 lines fetched + the same 3 dirtied (row pitch 225.5 lines) -> 384 B of line traffic per row
-            "periodic_x": {"rows": per_rows, "algorithmic_bytes": per_rows * 2 * H * 2 * 8, "line_bytes": per_rows * 384,
-                           "algorithmic_GBps": per_rows * 2 * H * 2 * 8 / (t_periodic * 1e-3) / 1e9,
-                           "line_GBps": per_rows * 384 / (t_periodic * 1e-3) / 1e9,
-                           "line_frac_of_hbm_peak": per_rows * 384 / (t_periodic * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "higher_is_better": True, "scaling": "weak" if (world == 1 or not strong) else "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("TripolarGrid 1/10deg metric precompute (3600x1800, Float64, halo 4) + fill_halo_regions! of 4 fields "
+                                    "c/u/v/zeta (3600x1800x75): zipper + periodic-x in one merged launch" if world == 1 else
+                                    f"BASELINE config 4: the 1/10deg globe (3600x1800x75, Float64, halo 4) as {world} latitude bands of {ny} rows: per-band "
+                                    "metric precompute + fill_halo_regions! of c/u/v/zeta (zipper on the north rank, periodic-x, RCCL y-seam exchange)"
+                                    if strong else
+                                    f"weak scaling (not a BASELINE config): {world} bands of 1800 rows of a 3600x{NY * world}x75 globe: per-band metric "
+                                    "precompute + fill_halo_regions! of c/u/v/zeta (zipper on the north rank, periodic-x, RCCL y-seam exchange)"),
+                       "global_size": list(gsize), "local_size": [NX, ny, NZ], "rows_per_rank": ny, "halo": [H, H, H],
+                       "fields": [s[0] for s in SPECS], "parallelism": f"latitude-bands x{world}"},
+            "precompute_cells_per_s": cells / (t_build * 1e-3),            # N > 1: all bands / the slowest rank's build
+            "precompute_ms": t_build, "fill_ms": t_fill_kernel, "fill_bracket_ms": t_fill_bracket,
+            "fill_GBps": fill_bytes / (t_fill_kernel * 1e-3) / 1e9 if t_fill_kernel else None,
         }
+        if world > 1:
+            seam_bytes = 4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8
+            hidden = max(0.0, min(1.0, (t_build + t_fillx - ms_per_step) / max(1e-9, min(t_build, t_fillx))))
+            line.update({
+                "overlap": "halo fill (local fill + seam exchange) on a side stream, concurrent with the grid build" if overlap else None,
+                "exchange_ms": t_exchange,                          # pack + send/recv + unpack, slowest rank
+                "fill_plus_exchange_ms": t_fillx, "exchange_over_build": t_exchange / t_build,
+                "overlap_hidden_frac": hidden if overlap else 0.0,  # share of the shorter of (build, fill + exchange) that the step hides
+                "exchange_transport": ("gloo, host-staged (rehearsal: timings meaningless)" if rehearse
+                                       else ("tpg_fill_halo_regions_distributed -> tpg_halo_exchange_y: librccl ncclSend/ncclRecv group, packed messages"
+                                             if comm is not None else "torch.distributed batch_isend_irecv (nccl = RCCL), packed messages [fallback]")),
+                "seam_message_bytes_per_direction": seam_bytes,
+                "seam_GBps_per_direction": seam_bytes / (t_exchange * 1e-3) / 1e9,
+                "note": "no multi-GPU curve exists until the driver runs one: this line is what each N prints"})
         line.update(aux)
         if fill_step is not None:
             line["fill_step"] = fill_step
-        traffic = None
+        traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):                                   # PMC traffic is only valid for the build it was measured on
             with open(tpath) as f:
                 tj = json.load(f)
-            src = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "csrc", "tpg_zipper.hip")
-            if os.path.exists(src) and tj.get("zipper_source_sha16") == hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]:
-                traffic = tj.get("k_zipper_cols_bytes_per_launch")
-        line["roofline"] = {"kernel": "k_zipper_cols<double,2,4> (4 fields x 75 levels, one launch" + (", on the north rank" if world > 1 else "") + ")", "bound": "hbm",
-                            "achieved": zbytes / (t_zip * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": zbytes / (t_zip * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
-                            "algorithmic_bytes_per_launch": zbytes, "launch_ms": t_zip}
-        if aux:
-            line["roofline"]["copy_ceiling_ms"] = aux["zipper_copy_ceiling_ms"]
-            line["roofline"]["cold_launch_over_copy_ceiling"] = aux["zipper_cold_ms"] / aux["zipper_copy_ceiling_ms"]
-        flops = 2333.0 * NX * (jend - jstart + 1)                           # FP64 add/mul/fma (fma = 2) per cell, PMC-counted
+            if os.path.exists(KERNEL_SOURCE) and tj.get("kernel_source_sha16") == hashlib.sha256(open(KERNEL_SOURCE, "rb").read()).hexdigest()[:16]:
+                traffic = {k: v.get("hbm_bytes_per_launch") for k, v in tj.get("kernels", {}).items()}
+        if world == 1:
+            tm = traffic.get("k_fill_merged")
+            line["roofline"] = {
+                "kernel": "k_fill_merged<double,2,4> (tpg_fill_halo_regions: 4 fields x 83 levels, zipper fold + periodic x, one launch)", "bound": "hbm",
+                "achieved": fill_bytes / (t_fill_kernel * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": fill_bytes / (t_fill_kernel * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": tm,
+                "algorithmic_bytes_per_launch": fill_bytes, "algorithmic_bytes_fold": zbytes, "algorithmic_bytes_periodic_x": pbytes,
+                "launch_ms": t_fill_kernel, "measured": "the kernel's own start/stop events on every timed step (hipExtLaunchKernelGGL)",
+                "traffic_frac": (tm / (t_fill_kernel * 1e-3) / 1e9 / HBM_PEAK_GBPS) if tm else None,
+                "note": "the periodic-x part moves 128 B per row but must fetch and dirty 3 whole 128-B lines per row pair (row pitch 225.5 lines): "
+                        "counter traffic is ~1.5x algorithmic and the launch sits at the device's line rate (DESIGN.md 6)"}
+            tz = traffic.get("k_zipper_cols")
+            line["roofline_fold"] = {
+                "kernel": "k_zipper_cols<double,2,4> (tpg_zipper_fill: the fold alone, 4 fields x 75 levels, one launch)", "bound": "hbm",
+                "achieved": zbytes / (fold * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": zbytes / (fold * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": tz,
+                "algorithmic_bytes_per_launch": zbytes, "launch_ms": fold,
+                "measured": f"the kernel's own start/stop events over {args.steps} launches in step context (build -> fold -> periodic x), after the timed steps"}
+            if aux:
+                line["roofline_fold"]["copy_ceiling_ms"] = aux["zipper_copy_ceiling_ms"]
+                line["roofline_fold"]["cold_launch_over_copy_ceiling"] = aux["zipper_cold_ms"] / aux["zipper_copy_ceiling_ms"]
+        else:
+            line["roofline"] = {
+                "kernel": "k_fill_merged<double,2,4> on the north rank (zipper fold + periodic x of its band, one launch)", "bound": "hbm",
+                "achieved": fill_bytes / (t_fill_kernel * 1e-3) / 1e9 if t_fill_kernel else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": fill_bytes / (t_fill_kernel * 1e-3) / 1e9 / HBM_PEAK_GBPS if t_fill_kernel else None, "traffic": None,
+                "algorithmic_bytes_per_launch": fill_bytes, "launch_ms": t_fill_kernel,
+                "measured": "the kernel's own start/stop events, instrumented pass after the timed steps"}
+        flops = 2333.0 * NX * ny                                                # FP64 add/mul/fma (fma = 2) per cell, PMC-counted
         line["roofline_precompute"] = {
-            "kernel": "tpg_build_grid (k_tables + k_cells_tile + k_halos)", "bound": "hbm",
+            "kernel": "tpg_build_grid (k_tables + k_cells_tile + k_halos)" + (", slowest rank" if world > 1 else ""), "bound": "hbm",
             "achieved": 160.0 * band_cells / (t_build * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+            "frac": 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("k_cells_tile"),
             "algorithmic_bytes_per_launch": 160 * band_cells,
             "fp64_tflops": flops / (t_build * 1e-3) / 1e12, "fp64_peak_tflops": FP64_VALU_PEAK_TFLOPS,
             "fp64_frac": flops / (t_build * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
@@ -489,7 +555,131 @@ def main():
         dist.destroy_process_group()
 
 
-def fill_step_config5(torch, osg, _lib, dev):
+def auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, sg, geom, p, out, out_ptrs, ws, hip_event, elapsed_ms):
+    """Measurements of their own, N = 1 only, before the warm-up steps: the fold and the merged fill by cache state, the
+    same-shape copy ceiling, Float32 fold / fill / build, BASELINE config 2, the geometry utilities."""
+    n = len(SPECS)
+    stream = _lib.current_stream_ptr(dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    flush = torch.zeros(1 << 27, dtype=torch.float64, device=dev)          # 1 GiB: evicts L2 + Infinity Cache
+    e0, e1 = hip_event(), hip_event()
+
+    def fold(evs):
+        _lib.check(lib.tpg_zipper_fill_timed(fptrs, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F64, stream, evs[0], evs[1]))
+
+    def merged(evs):
+        _lib.check(lib.tpg_fill_halo_regions_timed(fptrs, n, xl, yl, sg, *geom, 1, _lib.TPG_F64, stream, evs[0], evs[1]))
+
+    acc = {"cold_dirty": [], "cold_clean": [], "warm": [], "copy_cold_clean": [], "merged_cold_clean": [], "merged_cold_dirty": [], "merged_warm": []}
+    for it in range(22):
+        flush.add_(1.0)                                                     # predecessor leaves the caches full of dirty lines
+        fold((e0, e1)); acc["cold_dirty"].append(elapsed_ms(e0, e1))
+        flush.sum()                                                         # ... full of clean lines
+        fold((e0, e1)); acc["cold_clean"].append(elapsed_ms(e0, e1))
+        fold((e0, e1)); acc["warm"].append(elapsed_ms(e0, e1))              # back-to-back relaunch (Infinity-Cache resident)
+        flush.sum()
+        testlib.check(tlib.tpg_zipper_copy_probe(fptrs, n, yl, *geom, _lib.TPG_F64, stream, e0, e1))
+        acc["copy_cold_clean"].append(elapsed_ms(e0, e1))
+        flush.add_(1.0)
+        merged((e0, e1)); acc["merged_cold_dirty"].append(elapsed_ms(e0, e1))
+        flush.sum()
+        merged((e0, e1)); acc["merged_cold_clean"].append(elapsed_ms(e0, e1))
+        merged((e0, e1)); acc["merged_warm"].append(elapsed_ms(e0, e1))
+    med = {k: statistics.median(v[2:]) for k, v in acc.items()}             # first 2 rounds dropped
+    aux = {"zipper_cold_ms": med["cold_clean"], "zipper_cold_dirty_ms": med["cold_dirty"], "zipper_warm_ms": med["warm"],
+           "zipper_copy_ceiling_ms": med["copy_cold_clean"],
+           "fill_merged_cold_ms": med["merged_cold_clean"], "fill_merged_cold_dirty_ms": med["merged_cold_dirty"], "fill_merged_warm_ms": med["merged_warm"],
+           "zipper_states_note": "kernel start/stop events, median of 20: after a 1 GiB read-only pass (cold), after a 1 GiB "
+                                 "in-place write (cold_dirty), back-to-back relaunch (warm); zipper_* = the fold alone (k_zipper_cols), "
+                                 "fill_merged_* = the whole fill (k_fill_merged); copy_ceiling = the fold's launch shape and bytes as a "
+                                 "pure copy (tpg_zipper_copy_probe, test library), cold"}
+    del flush
+    for fid, f in enumerate(fields):                                        # the copy probe left unfolded halos behind
+        testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0x5EED + fid, 12345.0, *geom, _lib.TPG_F64, None))
+
+    # ---- Float32 (the reference tests FT in {Float32, Float64}, test/runtests.jl:10): fold, whole fill, build ----------------
+    flush = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
+    f32 = [torch.empty((NZ + 2 * H, NY + 2 * H, NX + 2 * H), dtype=torch.float32, device=dev) for _ in SPECS]
+    for fid, f in enumerate(f32):
+        testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0xF32 + fid, 12345.0, *geom, _lib.TPG_F32, None))
+    p32 = _lib.ptr_table(f32)
+    a32 = {"fold": [], "fill": []}
+    for it in range(12):
+        flush.sum()
+        _lib.check(lib.tpg_zipper_fill_timed(p32, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F32, stream, e0, e1)); a32["fold"].append(elapsed_ms(e0, e1))
+        flush.sum()
+        _lib.check(lib.tpg_fill_halo_regions_timed(p32, n, xl, yl, sg, *geom, 1, _lib.TPG_F32, stream, e0, e1)); a32["fill"].append(elapsed_ms(e0, e1))
+    del f32, flush
+    zb32 = sum(zipper_algorithmic_bytes(NX, NZ, H, s=4).values())
+    pb32 = periodic_algorithmic_bytes(NY, NZ, H, n, s=4)
+    t_fold32, t_fill32 = statistics.median(a32["fold"][2:]), statistics.median(a32["fill"][2:])
+    pf = _lib.TpgParams(NX, NY, NZ, H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F32, 1, NY, 0)
+    outf = [torch.empty((NY + 2 * H, NX + 2 * H), dtype=torch.float32, device=dev) for _ in _lib.ARRAY_NAMES]
+    ptrf = _lib.ptr_table(outf)
+    for _ in range(3):
+        _lib.check(lib.tpg_build_grid(C.byref(pf), ptrf, ws.data_ptr(), ws.numel(), stream))
+    b0, b1 = ev(), ev()
+    b0.record()
+    for _ in range(20):
+        _lib.check(lib.tpg_build_grid(C.byref(pf), ptrf, ws.data_ptr(), ws.numel(), stream))
+    b1.record(); torch.cuda.synchronize()
+    usf = b0.elapsed_time(b1) / 20 * 1e3
+    del outf
+    aux["float32"] = {
+        "fold_ms": t_fold32, "fold_algorithmic_bytes": zb32, "fold_frac_of_hbm_peak": zb32 / (t_fold32 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "fold_kernel": "k_zipper_cols<float,4,4>, 4 fields x 75 levels, cold, kernel events, median of 10",
+        "fill_ms": t_fill32, "fill_algorithmic_bytes": zb32 + pb32, "fill_frac_of_hbm_peak": (zb32 + pb32) / (t_fill32 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "fill_kernel": "k_fill_merged<float,4,4>, same fields, cold, kernel events, median of 10",
+        "build_us": usf, "build_cells_per_s": NX * NY / (usf * 1e-6), "build_store_GBps": 80.0 * (NX + 2 * H) * (NY + 2 * H) / (usf * 1e-6) / 1e9,
+        "build_note": "3600x1800 Float32 grid: the Float64 pipeline on Float32-rounded lambda tables, rounded once at the store (SURVEY A-1); 20 builds back to back"}
+    lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
+
+    # BASELINE config 2: the 1/4 degree (1440 x 720) Float64 metric precompute alone, 20 back-to-back builds
+    p2 = _lib.TpgParams(1440, 720, 1, H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F64, 1, 720, 0)
+    out2 = [torch.empty((720 + 2 * H, 1440 + 2 * H), dtype=torch.float64, device=dev) for _ in _lib.ARRAY_NAMES]
+    ptr2 = _lib.ptr_table(out2)
+    ws2 = torch.empty(int(lib.tpg_build_grid_workspace_bytes(C.byref(p2))), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        _lib.check(lib.tpg_build_grid(C.byref(p2), ptr2, ws2.data_ptr(), ws2.numel(), stream))
+    b0, b1 = ev(), ev()
+    b0.record()
+    for _ in range(20):
+        _lib.check(lib.tpg_build_grid(C.byref(p2), ptr2, ws2.data_ptr(), ws2.numel(), stream))
+    b1.record(); torch.cuda.synchronize()
+    us2 = b0.elapsed_time(b1) / 20 * 1e3
+    aux["config2_quarter_degree_build"] = {"size": [1440, 720, 1], "us_per_build": us2, "cells_per_s": 1440 * 720 / (us2 * 1e-6),
+                                           "store_GBps": 160.0 * 1448 * 728 / (us2 * 1e-6) / 1e9}
+    del out2, ws2
+    # SURVEY 8(f-4) geometry utilities at the bench's own size, on the grid arrays the warm-up build just has to produce
+    _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
+    arr = dict(zip(_lib.ARRAY_NAMES, out))
+    angle = torch.empty((NY, NX), dtype=torch.float64, device=dev)
+    uo, vo = torch.zeros_like(fields[0]), torch.zeros_like(fields[0])
+
+    def timed_us(fn, reps):
+        fn(); torch.cuda.synchronize()
+        t0_, t1_ = ev(), ev()
+        t0_.record()
+        for _ in range(reps):
+            fn()
+        t1_.record(); torch.cuda.synchronize()
+        return t0_.elapsed_time(t1_) / reps * 1e3
+
+    t_ang = timed_us(lambda: _lib.check(lib.tpg_nonorthogonality_angle(arr["lambda_ff"].data_ptr(), arr["phi_ff"].data_ptr(), None,
+                                                                       angle.data_ptr(), NX, NY, H, H, _lib.TPG_F64, stream)), 20)
+    t_rot = timed_us(lambda: _lib.check(lib.tpg_convert_frame(arr["phi_cf"].data_ptr(), arr["phi_fc"].data_ptr(), arr["dy_cc"].data_ptr(),
+                                                              arr["dx_cc"].data_ptr(), fields[0].data_ptr(), fields[1].data_ptr(),
+                                                              uo.data_ptr(), vo.data_ptr(), 0, *geom, _lib.TPG_F64, stream)), 5)
+    rot_bytes = 4 * NX * NY * NZ * 8                                        # 2 fields read + 2 written, interior cells
+    aux["geometry_utilities"] = {
+        "nonorthogonality_angle_us": t_ang, "nonorthogonality_max_abs_deg_unmasked": float(angle.abs().max()),
+        "convert_frame_us": t_rot, "convert_frame_algorithmic_bytes": rot_bytes,
+        "convert_frame_frac_of_hbm_peak": rot_bytes / (t_rot * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+    del angle, uo, vo
+    return aux
+
+
+def fill_step_config5(torch, osg, _lib, tlib, dev):
     """BASELINE config 5: the halo fills of ONE baroclinic step of a hydrostatic model with a split-explicit
     free surface on the 1/24 degree x 100 level tripolar grid (test/runtests.jl:46-77, examples/bickley_jet.jl:44-55):
       * one tupled fill of the 3-D prognostic fields (u, v, T, S, c): 5 x 32.3 GB of Float64 resident on one MI355X;
@@ -501,13 +691,12 @@ def fill_step_config5(torch, osg, _lib, dev):
     need = 5 * (Nx + 8) * (Ny + 8) * (Nz + 8) * 8 + 16e9
     if free < need:
         return {"skipped": f"needs {need / 1e9:.0f} GB of free HBM, {free / 1e9:.0f} GB available"}
-    lib = _lib.lib()
     grid = osg.TripolarGrid(osg.GPU(dev.index), torch.float64, size=size, halo=halo)
     ext = osg.TripolarGrid(osg.GPU(dev.index), torch.float64, size=(Nx, Ny, 1), halo=(halo[0], substeps + 1, halo[2]))
     f3 = (osg.XFaceField(grid), osg.YFaceField(grid), osg.CenterField(grid), osg.CenterField(grid), osg.CenterField(grid))
     f2 = (osg.Field((osg.Center, osg.Center, None), ext), osg.Field((osg.Face, osg.Center, None), ext), osg.Field((osg.Center, osg.Face, None), ext))
     for k, f in enumerate(f3 + f2):
-        _lib.check(lib.tpg_fill_synthetic(f.data.data_ptr(), 0xF5 + k, 12345.0, f.Nx, f.Ny, f.Nz, f.Hx, f.Hy, f.Hz, _lib.TPG_F64, None))
+        assert tlib.tpg_fill_synthetic(f.data.data_ptr(), 0xF5 + k, 12345.0, f.Nx, f.Ny, f.Nz, f.Hx, f.Hy, f.Hz, _lib.TPG_F64, None) == 0
 
     def timed(fn, reps):
         fn(); torch.cuda.synchronize()
@@ -523,16 +712,16 @@ def fill_step_config5(torch, osg, _lib, dev):
     t2 = timed(graph.replay, 20)
     specs3 = [("u", 1, 0, -1), ("v", 0, 1, -1), ("T", 0, 0, 1), ("S", 0, 0, 1), ("c", 0, 0, 1)]
     zb = sum(zipper_algorithmic_bytes(Nx, Nz, halo[1], specs3).values())
+    pb = periodic_algorithmic_bytes(Ny, Nz, halo[0], 5)
     rows = 5 * (Ny + 2 * halo[1]) * (Nz + 2 * halo[2])
-    pb = rows * 2 * halo[0] * 2 * 8
-    line_bytes = zb + rows * 384                                    # fold: whole lines anyway; periodic: 3 + 3 lines per row pair
-    out = {"workload": "1/24deg (8640x4320x100, halo 4, Float64): tupled fill_halo_regions!((u,v,T,S,c)) [zipper + periodic x] + "
+    out = {"workload": "1/24deg (8640x4320x100, halo 4, Float64): tupled fill_halo_regions!((u,v,T,S,c)) [one merged launch] + "
                        f"{substeps} sub-step fills of (eta,U,V) with north halo {substeps + 1} [one fused launch each, one HIP graph]",
            "fields_GB": sum(f.data.numel() for f in f3) * 8 / 1e9,
            "fill3d_us": t3, "substep_fills_us": t2, "substeps": substeps, "total_us": t3 + t2,
-           "fill3d_algorithmic_bytes": zb + pb, "fill3d_line_bytes": line_bytes,
+           "fill3d_algorithmic_bytes": zb + pb,
            "fill3d_algorithmic_frac_of_hbm_peak": (zb + pb) / (t3 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-           "fill3d_line_frac_of_hbm_peak": line_bytes / (t3 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+           # modelled, not counted: the periodic part touches 3 whole 128-B lines per row pair twice (fetch + write-back), the fold whole lines
+           "fill3d_modelled_line_ops": (zb // 128) + rows * 3, "fill3d_modelled_lines_per_ns": ((zb // 128) + rows * 3) / (t3 * 1e3),
            "substep_fill_us_each": t2 / substeps}
     del f3, f2, grid, ext, graph
     torch.cuda.synchronize()

@@ -15,23 +15,20 @@
  *  - all array memory is DEVICE memory owned by the caller (Julia GC / torch); the library
  *    never allocates or frees device memory and keeps no reference past stream completion.
  *  - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
- *    re-entrant, graph-capturable (except the RCCL exchange, see tpg_halo_exchange_y), thread-safe for distinct streams.
+ *    re-entrant, thread-safe for distinct streams, and capturable into a HIP graph -- except the RCCL seam exchange
+ *    (tpg_halo_exchange_y*, tpg_fill_halo_regions_distributed* with a seam), which REFUSES a capturing stream with
+ *    TPG_ERR_UNSUPPORTED instead of stalling.
  *  - array layout: column-major padded parent arrays, i fastest:
  *      2-D  A[i,j]   at  (i+Hx-1) + (Nx+2Hx) * (j+Hy-1)
  *      3-D  c[i,j,k] at  (i+Hx-1) + (Nx+2Hx) * ((j+Hy-1) + (Ny+2Hy) * (k+Hz-1))
  *    i.e. exactly the `parent` of Oceananigans' OffsetArrays.
  *  - element type selected by `ft`: TPG_F32 or TPG_F64.
  *
- * Tuning / cross-check knobs (environment; read ONCE, at the first call into the library, into an immutable
- * record -- tpg_reload_config() re-reads them; every setting gives identical results,
- * tests/test_gpu_variants.py, and none is needed in production):
- *    TPG_CELLS_VARIANT   cell kernel of tpg_build_grid: 3 LDS tile (default), 0 thread per cell (cross-check)
- *    TPG_BUILD_NT        1 streaming stores in tpg_build_grid (default), 0 plain stores
- *    TPG_ZIPPER_VARIANT  3 column work items (default), 0 row work items (the fallback kernels, everywhere)
- *    TPG_FILL_FUSED      0 never / 1 always (where valid) use the fused small-field fill
- *    TPG_FILL_MERGED     0 never use the merged large-field fill (zipper + periodic x in one launch)
- * The library holds no other mutable global state: a thread-local error string, the immutable knob record,
- * and the lazily bound librccl entry points (std::call_once).
+ *
+ * The library reads no environment variable and holds no mutable global state beyond a thread-local error string and the
+ * lazily bound librccl entry points (std::call_once).  Test / bench hooks (synthetic fill, the copy probe of the fold, the
+ * elementary-function probe) and the TPG_* cross-check knobs that force the fallback kernels live in a separate
+ * library, libtripolar_hip_test.so (include/tripolar_hip_test.h), which a host never loads.
  */
 #ifndef TRIPOLAR_HIP_H
 #define TRIPOLAR_HIP_H
@@ -43,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TPG_VERSION 200 /* 0.2.0 */
+#define TPG_VERSION 300 /* 0.3.0 */
 
 enum tpg_status {
     TPG_OK = 0,
@@ -90,7 +87,6 @@ typedef struct tpg_params {
 int tpg_version(void);
 const char *tpg_last_error(void);
 const char *tpg_status_string(int status);
-int tpg_reload_config(void); /* re-read the TPG_* knobs (tests; not for use while other threads are in the library) */
 
 /* ---- metric precompute ------------------------------------------------------------------
  * Replaces, in one call, src/tripolar_grid.jl:73-328: the 1-D tables (:76-97),
@@ -127,18 +123,13 @@ int tpg_zipper_fill(void *const fields[], int nfields,
 /* Same call, with the kernel's own start / stop device timestamps recorded into two HIP events
  * (hipExtLaunchKernelGGL): what bench.py uses for roofline.achieved, so that the live number is the
  * kernel duration rocprofv3 reports, free of stream-marker and launch-boundary overhead.
- * nfields <= TPG_MAX_FIELDS (one kernel).  Events: tpg_event_create / hipEventCreate. */
+ * nfields <= TPG_MAX_FIELDS (one kernel).  Events: tpg_event_create / hipEventCreate.  tpg_fill_halo_regions_timed (below)
+ * is the same for the whole fill: the events ride on the FIRST kernel the call launches, which is the only one whenever the
+ * fill is one merged or fused launch. */
 int tpg_zipper_fill_timed(void *const fields[], int nfields,
                           const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                           int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
                           int kstart, int kcount, int ft, void *stream,
-                          void *start_event, void *stop_event);
-/* Same-shape copy ceiling of the fold (bench.py `zipper_copy_ceiling_ms`): the launch of tpg_zipper_fill over
- * k = 1..Nz with identical rows, bytes and work decomposition, but destination column = source column and no
- * sign -- what a pure copy of the fold's bytes costs on this device.  OVERWRITES the north halo rows (and the
- * east half of row Ny of y-Center fields) with unfolded copies: benchmark use only.  No reference counterpart. */
-int tpg_zipper_copy_probe(void *const fields[], int nfields, const int8_t yloc[],
-                          int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream,
                           void *start_event, void *stop_event);
 int tpg_event_create(void **event);
 int tpg_event_destroy(void *event);
@@ -154,14 +145,17 @@ int tpg_periodic_x_fill(void *const fields[], int nfields,
  * 143-147,177-185), then periodic x.  Small fields (2-D free-surface / barotropic fields: fewer than 2^20
  * written cells per call) take ONE fused launch in which every written cell is computed from original
  * interior values through the composed index map; results are identical to the two-launch sequence.
- * TPG_FILL_FUSED=0 disables, =1 forces the fused form wherever Nx >= 2Hx+2 and Ny >= 2Hy+2.
  * Large fields with 16-B chunkable rows and Hy <= 8 take ONE merged launch as well: column-chunk fold blocks that also
- * write the corner cells (composed map) beside periodic-x blocks for all other rows (TPG_FILL_MERGED=0 disables);
+ * write the corner cells (composed map) beside periodic-x blocks for all other rows;
  * everything else runs tpg_zipper_fill then tpg_periodic_x_fill. */
 int tpg_fill_halo_regions(void *const fields[], int nfields,
                           const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                           int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
                           int north_is_zipper, int ft, void *stream);
+int tpg_fill_halo_regions_timed(void *const fields[], int nfields,
+                                const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                                int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
+                                int north_is_zipper, int ft, void *stream, void *start_event, void *stop_event);
 
 /* ---- latitude-band halo exchange helpers (config 4) -------------------------------------
  * The interior seams of a y-slab partition exchange Hy full rows (all i incl. x halos, all
@@ -185,8 +179,8 @@ int tpg_unpack_y_halo(void *const fields[], int nfields, const void *buffer, int
  * halo communication (src/distributed_tripolar_grid.jl:171 inject_halo_communication_boundary_conditions, :195
  * FieldBoundaryBuffers; MPI Isend/Irecv of one packed buffer per side [recalled]).  Here one call issues the whole
  * seam exchange of `nfields` fields of one geometry on `stream`: ONE ncclGroupStart/ncclGroupEnd of point-to-point
- * ncclSend/ncclRecv (RCCL over xGMI), no host wait, no collective.  NOT to be captured into a HIP graph: a capture attempt of this
- * call on the one-rank loop-back communicator did not complete (round 2); every other entry point is capture-safe.
+ * ncclSend/ncclRecv (RCCL over xGMI), no host wait, no collective.  A stream that is being captured into a HIP graph is
+ * refused (TPG_ERR_UNSUPPORTED): capture the local fill and issue the exchange eagerly.
  *   comm            ncclComm_t of the latitude-band chain (as void*): created by the host's RCCL binding, or by
  *                   tpg_comm_init_rank below (librccl is bound lazily with dlopen; TPG_ERR_RCCL if absent).
  *   rank, nranks    position in the chain: rank 0 is the southernmost band and has no south seam, rank nranks-1
@@ -195,10 +189,14 @@ int tpg_unpack_y_halo(void *const fields[], int nfields, const void *buffer, int
  *                   NULL): PACKED exchange = tpg_pack_y_halo -> one message per direction -> tpg_unpack_y_halo.
  *                   All four NULL: PACK-FREE exchange -- the Hy seam rows of one (field, level) are one contiguous
  *                   window of the parent array (Hy * (Nx+2Hx) elements), sent from / received into the fields
- *                   directly, (nfields * (Nz+2Hz)) send/recv pairs per direction inside the one group.
+ *                   directly, (nfields * (Nz+2Hz)) send/recv pairs per direction inside the one group.  Every pair is
+ *                   one RCCL operation (~3.4 us each on the loop-back): the pack-free form is for 2-D and few-level
+ *                   fields only; 3-D fields use the packed form (one operation per direction).
  * Call it after the zipper (north rank) and the periodic-x pass of the same fill, as the reference orders them.
  * tpg_halo_exchange_y_peers is the same with explicit peer ranks (-1 = no seam on that side). */
 #define TPG_COMM_ID_BYTES 128
+int tpg_comm_available(void);                                                    /* TPG_OK if librccl could be bound (no collective call):
+                                                                                    agree on this across ranks BEFORE tpg_comm_init_rank */
 int tpg_comm_unique_id(void *id128);                                             /* ncclGetUniqueId     */
 int tpg_comm_init_rank(void **comm, int nranks, const void *id128, int rank);    /* ncclCommInitRank on the current device */
 int tpg_comm_destroy(void *comm);                                                /* ncclCommDestroy     */
@@ -208,6 +206,22 @@ int tpg_halo_exchange_y(void *comm, int rank, int nranks, void *const fields[], 
 int tpg_halo_exchange_y_peers(void *comm, int south_peer, int north_peer, void *const fields[], int nfields,
                               void *send_south, void *send_north, void *recv_south, void *recv_north,
                               int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
+
+/* fill_halo_regions!(fields...) on a DistributedTripolarGrid, whole, in ONE call and in the reference's order
+ * (src/distributed_tripolar_grid.jl:143-147,177-185: the zipper only on the last rank; src/distributed_tripolar_grid.jl:171,195: every
+ * other south / north side is neighbour communication): zipper fold (rank nranks-1) -> periodic x (merged / fused launch where
+ * the geometry allows) -> tpg_halo_exchange_y, all enqueued on `stream`.  nranks = 1 is the serial fill (comm may be NULL).
+ * xloc / yloc / sign are read on the zipper rank only.  Buffers as for tpg_halo_exchange_y (all NULL = pack-free).
+ * The _peers form takes explicit neighbours (-1 = none) and the north side's kind, for hosts with their own rank map. */
+int tpg_fill_halo_regions_distributed(void *comm, int rank, int nranks, void *const fields[], int nfields,
+                                      const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                                      void *send_south, void *send_north, void *recv_south, void *recv_north,
+                                      int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
+int tpg_fill_halo_regions_distributed_peers(void *comm, int south_peer, int north_peer, int north_is_zipper,
+                                            void *const fields[], int nfields,
+                                            const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                                            void *send_south, void *send_north, void *recv_south, void *recv_north,
+                                            int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
 
 /* ---- geometry utilities over the grid arrays -------------------------------
  * tpg_nonorthogonality_angle: compute_nonorthogonality_angle! of test/test_tripolar_grid.jl:8-34 as launched at
@@ -224,21 +238,6 @@ int tpg_nonorthogonality_angle(const void *lambda_ff, const void *phi_ff, const 
 int tpg_convert_frame(const void *phi_cf, const void *phi_fc, const void *dy_cc, const void *dx_cc,
                       const void *u, const void *v, void *u_out, void *v_out, int to_native,
                       int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
-
-/* Deterministic synthetic field fill used by tests and bench.py:
- * interior (i,j,k) gets a splitmix64(seed, linear index) value in (-1,1); every halo cell gets
- * `halo_sentinel`.  Not part of the reference surface. */
-int tpg_fill_synthetic(void *field, uint64_t seed, double halo_sentinel,
-                       int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
-
-/* Validation hook (tests/test_gpu_math.py): evaluates one of the library's deterministic Float64
- * elementary functions (which = 0 sin, 1 cos, 2 sind, 3 cosd, 4 tand, 5 atan, 6 asin, 7 asinh, 8 sinh,
- * 9 cosh, 10 acos; 20 sqrt_nr(x), 21 div_nr over pairs x = (a0, b0, a1, b1, ...): the unscaled square root and
- * division of the metric kernel) or one of the straight-line batch forms used by the metric kernel (100 sin_small, 101 cos,
- * 102 atan, 103 atan_tab, 104 atan_small, 105 asin_small, 106 sind / 107 cosd of sincosd) on n device
- * doubles x -> y; rare[i] (int32) = 1 where a batch form reports "outside my fast domain".
- * No reference counterpart: these stand in for Julia Base / Distances arithmetic. */
-int tpg_math_probe(int which, const void *x, void *y, void *rare, long long n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -55,35 +55,47 @@ SIGNATURES = {
     "tpg_version": (_i, []),
     "tpg_last_error": (C.c_char_p, []),
     "tpg_status_string": (C.c_char_p, [_i]),
-    "tpg_reload_config": (_i, []),
     "tpg_build_grid_workspace_bytes": (_sz, [C.POINTER(TpgParams)]),
     "tpg_build_grid": (_i, [C.POINTER(TpgParams), C.POINTER(_vp), _vp, _sz, _vp]),
     "tpg_zipper_fill": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
                         + _geom + [_i, _i, _i, _vp]),
     "tpg_zipper_fill_timed": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
                               + _geom + [_i, _i, _i, _vp, _vp, _vp]),
-    "tpg_zipper_copy_probe": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8)] + _geom + [_i, _vp, _vp, _vp]),
     "tpg_event_create": (_i, [C.POINTER(_vp)]),
     "tpg_event_destroy": (_i, [_vp]),
     "tpg_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "tpg_periodic_x_fill": (_i, [C.POINTER(_vp), _i] + _geom + [_i, _vp]),
     "tpg_fill_halo_regions": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
                               + _geom + [_i, _i, _vp]),
+    "tpg_fill_halo_regions_timed": (_i, [C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32)]
+                                    + _geom + [_i, _i, _vp, _vp, _vp]),
     "tpg_y_halo_buffer_elems": (_sz, [_i] * 6),
     "tpg_pack_y_halo": (_i, [C.POINTER(_vp), _i, _vp, _i] + _geom + [_i, _vp]),
     "tpg_unpack_y_halo": (_i, [C.POINTER(_vp), _i, _vp, _i] + _geom + [_i, _vp]),
+    "tpg_comm_available": (_i, []),
     "tpg_comm_unique_id": (_i, [_vp]),
     "tpg_comm_init_rank": (_i, [C.POINTER(_vp), _i, _vp, _i]),
     "tpg_comm_destroy": (_i, [_vp]),
     "tpg_halo_exchange_y": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, _vp, _vp, _vp, _vp] + _geom + [_i, _vp]),
     "tpg_halo_exchange_y_peers": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, _vp, _vp, _vp, _vp] + _geom + [_i, _vp]),
+    "tpg_fill_halo_regions_distributed": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32),
+                                               _vp, _vp, _vp, _vp] + _geom + [_i, _vp]),
+    "tpg_fill_halo_regions_distributed_peers": (_i, [_vp, _i, _i, _i, C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8),
+                                                     C.POINTER(C.c_int32), _vp, _vp, _vp, _vp] + _geom + [_i, _vp]),
     "tpg_nonorthogonality_angle": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tpg_convert_frame": (_i, [_vp] * 8 + [_i] + _geom + [_i, _vp]),
-    "tpg_fill_synthetic": (_i, [_vp, C.c_uint64, C.c_double] + _geom + [_i, _vp]),
-    "tpg_math_probe": (_i, [_i, _vp, _vp, _vp, C.c_longlong, _vp]),
 }
 
 _lib = None
+
+
+def bind(path, signatures):
+    """dlopen `path` and declare `signatures` on it (AttributeError if the ABI is incomplete)"""
+    handle = C.CDLL(path)
+    for name, (restype, argtypes) in signatures.items():
+        fn = getattr(handle, name)
+        fn.restype, fn.argtypes = restype, argtypes
+    return handle
 
 
 def lib():
@@ -95,11 +107,7 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is the only backend of this package. "
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C orthogonalsphericalshellgrids.jl_amd/csrc`).")
-        handle = C.CDLL(LIB_PATH)
-        for name, (restype, argtypes) in SIGNATURES.items():
-            fn = getattr(handle, name)      # AttributeError if the ABI is incomplete
-            fn.restype, fn.argtypes = restype, argtypes
-        _lib = handle
+        _lib = bind(LIB_PATH, SIGNATURES)
     return _lib
 
 

@@ -17,6 +17,9 @@ void set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+#ifdef TPG_TEST_ABI
+// libtripolar_hip_test.so only: the cross-check / tuning knobs are read from the environment once, at the first call into
+// the library, into an immutable record; tpg_reload_config() publishes a fresh record atomically (tests).
 static std::atomic<const Config*> g_config{nullptr};
 static std::mutex g_config_mutex;
 
@@ -34,6 +37,7 @@ static const Config* read_config()
     c->zipper_variant = env_int("TPG_ZIPPER_VARIANT", 3) == 0 ? 0 : 3;
     c->fill_fused = env_int("TPG_FILL_FUSED", -1);
     c->fill_merged = env_int("TPG_FILL_MERGED", -1);
+    c->exchange_in_capture = env_int("TPG_EXCHANGE_IN_CAPTURE", 0) != 0;
     return c;
 }
 
@@ -47,6 +51,14 @@ const Config& config()
     }
     return *c;
 }
+#else
+// the product library has no knobs: one constant record, no environment access
+const Config& config()
+{
+    static const Config k{ 3, true, 3, -1, -1, false };
+    return k;
+}
+#endif
 
 int check_geom(int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft)
 {
@@ -77,12 +89,14 @@ extern "C" {
 
 int tpg_version(void) { return TPG_VERSION; }
 
+#ifdef TPG_TEST_ABI
 int tpg_reload_config(void)
 {
     std::lock_guard<std::mutex> lock(tpg::g_config_mutex);
     tpg::g_config.store(tpg::read_config(), std::memory_order_release);
     return TPG_OK;
 }
+#endif
 
 const char* tpg_last_error(void) { return tpg::g_err; }
 

@@ -42,14 +42,17 @@ inline Geom make_geom(int Nx, int Ny, int Nz, int Hx, int Hy, int Hz)
 
 int check_geom(int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft);
 
-// Tuning / cross-check knobs (include/tripolar_hip.h): read from the environment ONCE, at the first call into
-// the library, into an immutable record; tpg_reload_config() (tests) publishes a fresh record atomically.
+// Kernel-selection record.  The product library (libtripolar_hip.so) carries ONE constant record -- the defaults below, no
+// environment access.  The test library (libtripolar_hip_test.so, -DTPG_TEST_ABI) reads the TPG_* cross-check knobs of
+// include/tripolar_hip_test.h from the environment once into an immutable record; tpg_reload_config() publishes a fresh one.
 struct Config {
-    int cells_variant;   // TPG_CELLS_VARIANT  3 LDS-tile kernel (default), 0 thread-per-cell cross-check
-    bool build_nt;       // TPG_BUILD_NT       1 streaming stores in tpg_build_grid (default), 0 plain
-    int zipper_variant;  // TPG_ZIPPER_VARIANT 3 column items (default), 0 row items (the fallback kernels)
-    int fill_fused;      // TPG_FILL_FUSED     -1 automatic (default), 0 never, 1 wherever valid
-    int fill_merged;     // TPG_FILL_MERGED    -1 automatic (default), 0 never, 1 wherever valid
+    int cells_variant;        // TPG_CELLS_VARIANT  3 LDS-tile kernel (default), 0 thread-per-cell cross-check
+    bool build_nt;            // TPG_BUILD_NT       1 streaming stores in tpg_build_grid (default), 0 plain
+    int zipper_variant;       // TPG_ZIPPER_VARIANT 3 column items (default), 0 row items (the fallback kernels)
+    int fill_fused;           // TPG_FILL_FUSED     -1 automatic (default), 0 never, 1 wherever valid
+    int fill_merged;          // TPG_FILL_MERGED    -1 automatic (default), 0 never, 1 wherever valid
+    bool exchange_in_capture; // TPG_EXCHANGE_IN_CAPTURE  0 (default): the RCCL seam exchange refuses a capturing stream; 1: lets it through
+                              //                          (tools/rccl_capture_probe.py, the diagnostic of the round-2 capture stall)
 };
 const Config& config();
 

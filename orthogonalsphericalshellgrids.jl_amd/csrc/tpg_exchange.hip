@@ -6,7 +6,9 @@
 // halos, all levels incl. the z halos) in both directions.  The reference's transport is MPI Isend/Irecv of one
 // packed buffer per side [recalled]; here it is ONE ncclGroupStart/ncclGroupEnd of point-to-point
 // ncclSend/ncclRecv on the caller's stream: no host wait, no collective (a y-slab chain only talks to its two
-// neighbours).  (Not graph-capturable in practice: a capture attempt on the loop-back communicator hung, round 2.)  Two message shapes:
+// neighbours).  The exchange refuses a stream that is being captured into a HIP graph (TPG_ERR_UNSUPPORTED): RCCL's group
+// launch does its own stream / event work and, on a peer's first use, allocations -- tools/rccl_capture_probe.py is the
+// phase-by-phase record of what happens otherwise.  Two message shapes:
 //   packed    : tpg_pack_y_halo -> one message per seam direction ([field][level][Hy][sx], 9.58 MB per field at
 //               1/10 deg x 75 levels) -> tpg_unpack_y_halo;
 //   pack-free : the Hy seam rows of one (field, level) are already one contiguous window of the parent array
@@ -82,6 +84,11 @@ int nccl_status(const Rccl* r, ncclResult_t e, const char* what)
 
 extern "C" {
 
+int tpg_comm_available(void)
+{
+    return rccl() ? TPG_OK : TPG_ERR_RCCL;
+}
+
 int tpg_comm_unique_id(void* id128)
 {
     if (!id128) { tpg::set_error("null id buffer"); return TPG_ERR_INVALID_ARGUMENT; }
@@ -132,6 +139,18 @@ int tpg_halo_exchange_y_peers(void* comm, int south_peer, int north_peer, void* 
     if (!r) return TPG_ERR_RCCL;
     ncclComm_t c = static_cast<ncclComm_t>(comm);
     hipStream_t s = tpg::as_stream(stream);
+    {
+        // capture fence: an RCCL group enqueued into a stream capture stalls or invalidates the capture;
+        // a host that wants graphs captures the local part of the fill and issues the exchange eagerly between replays
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const hipError_t ce = hipStreamIsCapturing(s, &cs);
+        if (ce != hipSuccess) (void)hipGetLastError();               // e.g. the legacy stream while another stream captures in global mode
+        if ((ce != hipSuccess || cs != hipStreamCaptureStatusNone) && !tpg::config().exchange_in_capture) {
+            tpg::set_error("tpg_halo_exchange_y: the stream is being captured into a HIP graph; the RCCL seam exchange is not capturable "
+                           "(capture the local fill, issue the exchange eagerly)");
+            return TPG_ERR_UNSUPPORTED;
+        }
+    }
     const ncclDataType_t dt = ft == TPG_F64 ? ncclFloat64 : ncclFloat32;
     const size_t esz = ft == TPG_F64 ? 8 : 4;
     const size_t sx = (size_t)Nx + 2 * Hx, sy = (size_t)Ny + 2 * Hy, nlev = (size_t)Nz + 2 * Hz;
@@ -183,6 +202,42 @@ int tpg_halo_exchange_y(void* comm, int rank, int nranks, void* const fields[], 
     // rank 0 is the southernmost band, rank nranks-1 owns the zipper: neither of those two sides communicates
     return tpg_halo_exchange_y_peers(comm, rank > 0 ? rank - 1 : -1, rank < nranks - 1 ? rank + 1 : -1, fields, nfields,
                                      send_south, send_north, recv_south, recv_north, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream);
+}
+
+// fill_halo_regions! of fields on a DistributedTripolarGrid, whole, in the reference's order
+// (src/distributed_tripolar_grid.jl:143-147,177-185: the zipper only where the north side is the fold, i.e. on the last
+// rank; every other south / north side is neighbour communication): zipper -> periodic x (one merged or fused launch where
+// the geometry allows) -> the seam exchange, all enqueued on `stream`.
+int tpg_fill_halo_regions_distributed_peers(void* comm, int south_peer, int north_peer, int north_is_zipper,
+                                            void* const fields[], int nfields,
+                                            const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                                            void* send_south, void* send_north, void* recv_south, void* recv_north,
+                                            int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream)
+{
+    if (north_is_zipper && north_peer >= 0) {
+        tpg::set_error("the north side is either the zipper or a seam, not both (north_peer %d)", north_peer);
+        return TPG_ERR_INVALID_ARGUMENT;
+    }
+    if (nfields > TPG_MAX_FIELDS && (south_peer >= 0 || north_peer >= 0)) {
+        tpg::set_error("at most %d fields per distributed fill (one seam message per side)", TPG_MAX_FIELDS);
+        return TPG_ERR_UNSUPPORTED;
+    }
+    int rc = tpg_fill_halo_regions(fields, nfields, xloc, yloc, sign, Nx, Ny, Nz, Hx, Hy, Hz, north_is_zipper ? 1 : 0, ft, stream);
+    if (rc) return rc;
+    if (south_peer < 0 && north_peer < 0) return TPG_OK;           // a one-band chain: the serial fill
+    return tpg_halo_exchange_y_peers(comm, south_peer, north_peer, fields, nfields, send_south, send_north, recv_south, recv_north,
+                                     Nx, Ny, Nz, Hx, Hy, Hz, ft, stream);
+}
+
+int tpg_fill_halo_regions_distributed(void* comm, int rank, int nranks, void* const fields[], int nfields,
+                                      const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                                      void* send_south, void* send_north, void* recv_south, void* recv_north,
+                                      int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks) { tpg::set_error("rank %d outside 0:%d", rank, nranks - 1); return TPG_ERR_BAD_PARTITION; }
+    return tpg_fill_halo_regions_distributed_peers(comm, rank > 0 ? rank - 1 : -1, rank < nranks - 1 ? rank + 1 : -1, rank == nranks - 1,
+                                                   fields, nfields, xloc, yloc, sign, send_south, send_north, recv_south, recv_north,
+                                                   Nx, Ny, Nz, Hx, Hy, Hz, ft, stream);
 }
 
 }  // extern "C"

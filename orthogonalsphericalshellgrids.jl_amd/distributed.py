@@ -126,10 +126,22 @@ class RcclComm:
         _lib.check(_lib.lib().tpg_comm_init_rank(C.byref(comm), nranks, C.cast(buf, C.c_void_p), rank))
         return cls(comm, rank, nranks)
 
+    @staticmethod
+    def available() -> bool:
+        """librccl can be bound on this rank (no collective call): agree on it across ranks before create()"""
+        return _lib.lib().tpg_comm_available() == 0
+
     @classmethod
     def from_torch(cls, group=None):
+        """Collective over `group`.  Every rank first reports whether it can bind librccl and all ranks agree (a MIN
+        reduction of the flag through all_gather_object) BEFORE anyone enters the collective ncclCommInitRank: a rank that
+        cannot would otherwise leave the others blocked inside it."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(cls.available()), group=group)
+        if not all(flags):
+            raise RuntimeError(f"librccl unavailable on rank(s) {[r for r, ok in enumerate(flags) if not ok]}: no communicator created")
         box = [None]
         if rank == 0:
             try:
@@ -152,86 +164,99 @@ def message_shape(nfields, f):
     return (nfields, f.Nz + 2 * f.Hz, f.Hy, f.Nx + 2 * f.Hx)
 
 
-_BUFFERS: Dict[tuple, Dict[str, Dict[int, torch.Tensor]]] = {}
+class SeamBuffers:
+    """send / recv message buffers of ONE batch (<= TPG_MAX_FIELDS fields of one geometry) of ONE exchange object.
+    They belong to the PendingExchange (and through it to the HaloFillPlan) that created them -- never to a module-level
+    cache: two plans of equal geometry, or two batches of one plan, that are in flight together (begun before either is
+    finished, or enqueued on different streams) must not share staging memory.  Allocated once, reused every fill."""
 
+    def __init__(self, shape, dtype, device, plan):
+        self.send = {m.side: torch.empty(shape, dtype=dtype, device=device) for m in plan}
+        self.recv = {m.side: torch.empty(shape, dtype=dtype, device=device) for m in plan}
 
-def _message_buffers(shape, dtype, device, plan):
-    """send / recv message buffers, kept across fills (a halo fill runs every time step: no
-    allocator traffic on the hot path; one pair per seam side, geometry, dtype and device)"""
-    key = (tuple(shape), dtype, str(device), tuple(m.side for m in plan))
-    bufs = _BUFFERS.get(key)
-    if bufs is None:
-        bufs = {"send": {m.side: torch.empty(shape, dtype=dtype, device=device) for m in plan},
-                "recv": {m.side: torch.empty(shape, dtype=dtype, device=device) for m in plan}}
-        _BUFFERS[key] = bufs
-    return bufs["send"], bufs["recv"]
+    def ptr(self, which, side):
+        d = self.send if which == "send" else self.recv
+        return None if side not in d else d[side].data_ptr()
 
 
 class PendingExchange:
-    """A posted seam exchange: begin = pack + post, finish = wait + unpack.  Splitting the two lets a single
-    process drive several emulated ranks (all post, then all finish) and lets a caller put work between them."""
+    """The seam exchange of one group of fields (one geometry): begin = pack + post, finish = wait + unpack.  Splitting the
+    two lets a single process drive several emulated ranks (all post, then all finish) and lets a caller put work between
+    them.  The object is reusable (a HaloFillPlan keeps one per geometry group and runs it every step) and owns its message
+    buffers, one SeamBuffers per batch of TPG_MAX_FIELDS fields.
+
+    With an RcclComm on the architecture (and no explicit transport) the exchange is the C ABI's: `run()` = ONE call of
+    tpg_halo_exchange_y per batch (pack -> RCCL send/recv group -> unpack on the current stream, no host wait);
+    begin() then does nothing and finish() runs it."""
 
     def __init__(self, fields, arch, transport=None, pack_free=False):
         self.plan = exchange_plan(arch.local_rank, arch.ranks[1])
         self.fields, self.arch = list(fields), arch
         self.comm = getattr(arch, "rccl_comm", None) if transport is None else None
         self.transport = transport if transport is not None else torch_distributed_transport
-        self.pack_free = pack_free
-        self._batches = []
-
-    def begin(self):
+        self.pack_free = pack_free and self.comm is not None
+        self._handles = None
+        self.batches = []                     # (fields, pointer table, SeamBuffers or None)
         if not self.plan:
-            return self
-        lib = _lib.lib()
+            return
         f0 = self.fields[0]
-        geom = (f0.Nx, f0.Ny, f0.Nz, f0.Hx, f0.Hy, f0.Hz)
-        ft = _lib.ft_of(f0.data.dtype)
-        dev = f0.data.device
+        self.geom = (f0.Nx, f0.Ny, f0.Nz, f0.Hx, f0.Hy, f0.Hz)
+        self.ft = _lib.ft_of(f0.data.dtype)
+        self.device = f0.data.device
         for b0 in range(0, len(self.fields), _lib.TPG_MAX_FIELDS):
             batch = self.fields[b0:b0 + _lib.TPG_MAX_FIELDS]
-            ptrs = _lib.ptr_table([f.data for f in batch])
-            if self.comm is not None and self.pack_free:
-                self._batches.append((batch, ptrs, None, None, None))
-                continue
-            send, recv = _message_buffers(message_shape(len(batch), f0), f0.data.dtype, dev, self.plan)
-            handle = None
-            if self.comm is None:
-                with torch.cuda.device(dev):
-                    stream = _lib.current_stream_ptr(dev)
-                    for m in self.plan:
-                        _lib.check(lib.tpg_pack_y_halo(ptrs, len(batch), send[m.side].data_ptr(), m.side, *geom, ft, stream))
-                    if hasattr(self.transport, "post"):
-                        handle = self.transport.post(self.plan, send, recv, getattr(self.arch, "process_group", None))
-            self._batches.append((batch, ptrs, send, recv, handle))
+            bufs = None if self.pack_free else SeamBuffers(message_shape(len(batch), f0), f0.data.dtype, self.device, self.plan)
+            self.batches.append((batch, _lib.ptr_table([f.data for f in batch]), bufs))
+
+    def run(self):
+        """RCCL path: the whole exchange of every batch, enqueued on the current stream"""
+        lib = _lib.lib()
+        with torch.cuda.device(self.device):
+            stream = _lib.current_stream_ptr(self.device)
+            for batch, ptrs, bufs in self.batches:
+                p = (lambda w, side: None) if bufs is None else bufs.ptr
+                _lib.check(lib.tpg_halo_exchange_y(self.comm.handle, self.arch.local_rank, self.arch.ranks[1], ptrs, len(batch),
+                                                   p("send", SOUTH), p("send", NORTH), p("recv", SOUTH), p("recv", NORTH),
+                                                   *self.geom, self.ft, stream))
+
+    def begin(self):
+        if not self.plan or self.comm is not None:
+            return self
+        if self._handles is not None:
+            raise RuntimeError("PendingExchange.begin() called twice without finish(): its message buffers are still in flight")
+        lib = _lib.lib()
+        group = getattr(self.arch, "process_group", None)
+        self._handles = []
+        with torch.cuda.device(self.device):
+            stream = _lib.current_stream_ptr(self.device)
+            for batch, ptrs, bufs in self.batches:
+                for m in self.plan:
+                    _lib.check(lib.tpg_pack_y_halo(ptrs, len(batch), bufs.send[m.side].data_ptr(), m.side, *self.geom, self.ft, stream))
+                self._handles.append(self.transport.post(self.plan, bufs.send, bufs.recv, group) if hasattr(self.transport, "post") else None)
         return self
 
     def finish(self):
         if not self.plan:
             return
+        if self.comm is not None:
+            return self.run()
+        if self._handles is None:
+            raise RuntimeError("PendingExchange.finish() without begin()")
         lib = _lib.lib()
-        f0 = self.fields[0]
-        geom = (f0.Nx, f0.Ny, f0.Nz, f0.Hx, f0.Hy, f0.Hz)
-        ft = _lib.ft_of(f0.data.dtype)
-        dev = f0.data.device
-        with torch.cuda.device(dev):
-            stream = _lib.current_stream_ptr(dev)
-            for batch, ptrs, send, recv, handle in self._batches:
-                if self.comm is not None:
-                    # the C ABI's exchange: pack -> one RCCL send/recv group -> unpack, all on `stream`, no host wait
-                    p = lambda d, side: None if d is None or side not in d else d[side].data_ptr()
-                    _lib.check(lib.tpg_halo_exchange_y(self.comm.handle, self.arch.local_rank, self.arch.ranks[1], ptrs, len(batch),
-                                                       p(send, SOUTH), p(send, NORTH), p(recv, SOUTH), p(recv, NORTH), *geom, ft, stream))
-                    continue
-                group = getattr(self.arch, "process_group", None)
+        group = getattr(self.arch, "process_group", None)
+        with torch.cuda.device(self.device):
+            stream = _lib.current_stream_ptr(self.device)
+            for (batch, ptrs, bufs), handle in zip(self.batches, self._handles):
                 if hasattr(self.transport, "post"):
                     self.transport.wait(handle)
                 else:
-                    self.transport(self.plan, send, recv, group)
+                    self.transport(self.plan, bufs.send, bufs.recv, group)
                 for m in self.plan:
-                    _lib.check(lib.tpg_unpack_y_halo(ptrs, len(batch), recv[m.side].data_ptr(), m.side, *geom, ft, stream))
-        self._batches = []
+                    _lib.check(lib.tpg_unpack_y_halo(ptrs, len(batch), bufs.recv[m.side].data_ptr(), m.side, *self.geom, self.ft, stream))
+        self._handles = None
 
 
 def exchange_y_halos(fields, arch, transport: Optional[Callable] = None, pack_free: bool = False):
-    """Fill the y-seam halo rows of `fields` (one geometry) from the neighbour ranks."""
+    """Fill the y-seam halo rows of `fields` (one geometry) from the neighbour ranks (one-off: allocates its message
+    buffers; keep a PendingExchange / HaloFillPlan for repeated fills)."""
     PendingExchange(fields, arch, transport, pack_free).begin().finish()

@@ -206,8 +206,8 @@ class HaloFillPlan:
         self.fields = list(fields)
         self._exchange = exchange
         self._pack_free = pack_free
-        self._pending = []
-        self._steps = []                      # (device, [(c function, argument tuple without the stream)], seam fields, arch)
+        self._steps = []                      # (device, [(c function, argument tuple without the stream)], PendingExchange or None)
+        self._keep = []                       # message buffers referenced by raw pointer from the argument tuples
         lib = _lib.lib()
         for f in self.fields:
             if f.boundary_conditions is not None:
@@ -219,25 +219,49 @@ class HaloFillPlan:
             zip_fs = [f for f in fs if is_zipper(f.boundary_conditions.north)]
             ft = _lib.ft_of(f0.data.dtype)
             geom = (f0.Nx, f0.Ny, f0.Nz, f0.Hx, f0.Hy, f0.Hz)
-            calls = []
-            if zip_fs and len(zip_fs) == len(fs):
-                # the usual case: one entry point for zipper -> periodic x (a single fused launch for small
-                # fields such as the 2-D free-surface / barotropic fields, two launches otherwise)
-                xl, yl, sg = _tables(fs)
-                calls.append((lib.tpg_fill_halo_regions, (_lib.ptr_table([f.data for f in fs]), len(fs), xl, yl, sg, *geom, 1, ft)))
+            distributed = getattr(arch, "is_distributed", False) and arch.ranks[1] > 1
+            comm = getattr(arch, "rccl_comm", None) if (distributed and exchange is None) else None
+            uniform = len(zip_fs) in (0, len(fs))
+            calls, pending = [], None
+            if comm is not None and uniform and (bool(zip_fs) == (arch.local_rank == arch.ranks[1] - 1)):
+                # the production path of a DistributedTripolarGrid: ONE C call per batch of <= TPG_MAX_FIELDS fields does the whole
+                # fill_halo_regions! -- zipper (last rank) -> periodic x -> RCCL seam exchange -- on the current stream
+                from .distributed import NORTH, SOUTH, SeamBuffers, exchange_plan, message_shape
+                plan = exchange_plan(arch.local_rank, arch.ranks[1])
+                for b0 in range(0, len(fs), _lib.TPG_MAX_FIELDS):
+                    batch = fs[b0:b0 + _lib.TPG_MAX_FIELDS]
+                    xl, yl, sg = _tables(batch) if zip_fs else (None, None, None)
+                    bufs = None if pack_free else SeamBuffers(message_shape(len(batch), f0), f0.data.dtype, f0.data.device, plan)
+                    self._keep.append(bufs)
+                    p = (lambda w, side: None) if bufs is None else bufs.ptr
+                    calls.append((lib.tpg_fill_halo_regions_distributed,
+                                  (comm.handle, arch.local_rank, arch.ranks[1], _lib.ptr_table([f.data for f in batch]), len(batch), xl, yl, sg,
+                                   p("send", SOUTH), p("send", NORTH), p("recv", SOUTH), p("recv", NORTH), *geom, ft)))
             else:
-                if zip_fs:
-                    xl, yl, sg = _tables(zip_fs)
-                    calls.append((lib.tpg_zipper_fill, (_lib.ptr_table([f.data for f in zip_fs]), len(zip_fs), xl, yl, sg,
-                                                        *geom, 1, f0.Nz, ft)))
-                calls.append((lib.tpg_periodic_x_fill, (_lib.ptr_table([f.data for f in fs]), len(fs), *geom, ft)))
-            seam = fs if getattr(arch, "is_distributed", False) and arch.ranks[1] > 1 else None
-            self._steps.append((f0.data.device, calls, seam, arch))
+                if zip_fs and len(zip_fs) == len(fs):
+                    # the usual case: one entry point for zipper -> periodic x (a single fused launch for small
+                    # fields such as the 2-D free-surface / barotropic fields, a single merged launch for large ones)
+                    xl, yl, sg = _tables(fs)
+                    calls.append((lib.tpg_fill_halo_regions, (_lib.ptr_table([f.data for f in fs]), len(fs), xl, yl, sg, *geom, 1, ft)))
+                else:
+                    if zip_fs:
+                        xl, yl, sg = _tables(zip_fs)
+                        calls.append((lib.tpg_zipper_fill, (_lib.ptr_table([f.data for f in zip_fs]), len(zip_fs), xl, yl, sg,
+                                                            *geom, 1, f0.Nz, ft)))
+                    calls.append((lib.tpg_periodic_x_fill, (_lib.ptr_table([f.data for f in fs]), len(fs), *geom, ft)))
+                if distributed:
+                    from .distributed import PendingExchange
+                    pending = PendingExchange(fs, arch, exchange, pack_free)     # owns its message buffers; reused every fill
+            self._steps.append((f0.data.device, calls, pending))
+
+    @property
+    def is_distributed(self):
+        return any(p is not None for _, _, p in self._steps) or bool(self._keep)
 
     def begin(self):
-        """local part of the fill (zipper, periodic x) on every geometry group, then pack + post of the seam exchange"""
-        self._pending = []
-        for device, calls, seam, arch in self._steps:
+        """local part of the fill (zipper, periodic x) on every geometry group, then pack + post of the seam exchange
+        (on the RCCL path the one C call has done the whole fill, exchange included, by the time begin() returns)"""
+        for device, calls, pending in self._steps:
             if torch.cuda.current_device() == device.index:     # the common case: no device switch to pay for
                 stream = _lib.current_stream_ptr(device)
                 for fn, args in calls:
@@ -247,16 +271,15 @@ class HaloFillPlan:
                     stream = _lib.current_stream_ptr(device)
                     for fn, args in calls:
                         _lib.check(fn(*args, stream))
-            if seam is not None:
-                from .distributed import PendingExchange
-                self._pending.append(PendingExchange(seam, arch, self._exchange, self._pack_free).begin())
+            if pending is not None:
+                pending.begin()
         return self
 
     def finish(self):
         """delivery + unpack of the seam messages posted by begin()"""
-        for p in self._pending:
-            p.finish()
-        self._pending = []
+        for _, _, pending in self._steps:
+            if pending is not None:
+                pending.finish()
         return None
 
     def __call__(self):
@@ -267,9 +290,9 @@ class HaloFillPlan:
         """Capture `repeat` consecutive runs of this plan into one HIP graph (torch.cuda.CUDAGraph) and return
         it; `graph.replay()` then issues the whole sequence with a single launch -- the fills of a
         split-explicit sub-cycle are launch-bound, 2.7 us instead of 7 us per fill.
-        Serial grids only: a seam exchange cannot be captured (torch.distributed cannot, and a capture attempt of the C ABI's RCCL
-        exchange on the one-rank loop-back communicator did not complete -- DESIGN.md 5)."""
-        if any(seam is not None for _, _, seam, _ in self._steps):
+        Serial grids only: a seam exchange cannot be captured (torch.distributed cannot, and the C ABI's RCCL exchange refuses a
+        capturing stream -- DESIGN.md 5)."""
+        if self.is_distributed:
             raise ValueError("HaloFillPlan.graph: plans with a distributed seam exchange cannot be captured")
         self()                                           # first-call work (occupancy queries, lazy module load) outside the capture
         torch.cuda.synchronize()

@@ -23,7 +23,7 @@ def _native_libraries_built():
     """A fresh checkout has no built .so (they are git-ignored): build once per session, exactly as
     the driver's __graft_entry__.build() does.  The package itself never builds or falls back."""
     lib = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "libtripolar_hip.so")
-    if not os.path.exists(lib):
+    if not os.path.exists(lib) or not os.path.exists(os.path.join(ROOT, "tools", "libtripolar_hip_test.so")):
         import __graft_entry__
         __graft_entry__.build()
 
@@ -46,6 +46,21 @@ def kats():
 def osg():
     import orthogonalsphericalshellgrids.jl_amd as m
     return m
+
+
+@pytest.fixture(scope="session")
+def tlib():
+    """tools/libtripolar_hip_test.so: the product's objects + the test-only hooks (include/tripolar_hip_test.h)"""
+    from tools import testlib
+    return testlib.lib()
+
+
+@pytest.fixture
+def via_testlib():
+    """the package's own calls go through the test library for this test (the TPG_* cross-check knobs live there)"""
+    from tools import testlib
+    with testlib.active() as handle:
+        yield handle
 
 
 @pytest.fixture(scope="session")

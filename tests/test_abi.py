@@ -10,10 +10,19 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "tripolar_hip.h")).read()
+def declared_symbols(header="tripolar_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(tpg_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+
+
+TEST_ONLY = ["tpg_fill_synthetic", "tpg_math_probe", "tpg_reload_config", "tpg_zipper_copy_probe"]
 
 
 def test_header_symbols_are_all_exported_and_bound(osg):
@@ -26,9 +35,27 @@ def test_header_symbols_are_all_exported_and_bound(osg):
     assert sorted(osg._lib.SIGNATURES) == names
 
 
+def test_product_library_exports_exactly_the_reference_facing_abi(osg):
+    """libtripolar_hip.so exports the symbols of include/tripolar_hip.h and NOTHING else: no test / bench hook, no C++ symbol,
+    no knob reload; the hooks live in tools/libtripolar_hip_test.so (include/tripolar_hip_test.h) = product symbols + 4"""
+    product = exported_symbols(osg._lib.LIB_PATH)
+    assert product == declared_symbols()
+    assert not set(product) & set(TEST_ONLY)
+    from tools import testlib
+    assert declared_symbols("tripolar_hip_test.h") == TEST_ONLY
+    assert exported_symbols(testlib.LIB_PATH) == sorted(product + TEST_ONLY)
+    assert sorted(testlib.TEST_SIGNATURES) == TEST_ONLY
+    # the product library never touches the environment: no getenv import
+    import subprocess
+    und = subprocess.run(["nm", "-D", "--undefined-only", osg._lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    und_t = subprocess.run(["nm", "-D", "--undefined-only", testlib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" in und_t
+
+
 def test_version_and_status_strings(osg):
     lib = osg._lib.lib()
-    assert lib.tpg_version() == 200
+    assert lib.tpg_version() == 300
     assert b"even" in lib.tpg_status_string(-2)
     assert lib.tpg_status_string(0) == b"ok"
 
@@ -69,6 +96,21 @@ def test_zipper_argument_errors_without_device_work(osg):
     assert lib.tpg_y_halo_buffer_elems(4, 3600, 75, 4, 4, 4) == 4 * 3608 * 4 * 83
 
 
+def test_distributed_fill_argument_errors_without_device_work(osg):
+    lib = osg._lib.lib()
+    fields = (C.c_void_p * 1)(1 << 20)
+    xl, yl, sg = (C.c_int8 * 1)(0), (C.c_int8 * 1)(0), (C.c_int32 * 1)(1)
+    geom = (10, 10, 1, 4, 4, 4)
+    assert lib.tpg_fill_halo_regions_distributed(None, 2, 2, fields, 1, xl, yl, sg, None, None, None, None, *geom, 1, None) == -3
+    assert lib.tpg_fill_halo_regions_distributed(None, -1, 2, fields, 1, xl, yl, sg, None, None, None, None, *geom, 1, None) == -3
+    # the north side is the zipper OR a seam
+    assert lib.tpg_fill_halo_regions_distributed_peers(None, -1, 1, 1, fields, 1, xl, yl, sg, None, None, None, None, *geom, 1, None) == -1
+    assert b"zipper or a seam" in lib.tpg_last_error()
+    # argument validation of the local fill comes first (odd Nx), before any communicator is looked at
+    assert lib.tpg_fill_halo_regions_distributed(None, 0, 2, fields, 1, xl, yl, sg, None, None, None, None, 11, 10, 1, 4, 4, 4, 1, None) == -2
+    assert lib.tpg_comm_available() in (0, -7)
+
+
 def test_product_has_no_cpu_path(osg):
     """without a HIP device the host API must fail loudly instead of computing on the CPU"""
     import torch
@@ -98,11 +140,11 @@ def test_product_does_not_import_the_oracle():
 
 
 def test_header_is_plain_c(tmp_path):
-    """include/tripolar_hip.h must compile as C99 with no C++ or HIP types (the boundary a Julia ccall / cgo / JNI stub binds)"""
+    """include/tripolar_hip.h (and the test header on top of it) must compile as C99 with no C++ or HIP types (the boundary a Julia ccall / cgo / JNI stub binds)"""
     import subprocess
-    names = declared_symbols()
+    names = declared_symbols() + declared_symbols("tripolar_hip_test.h")
     src = tmp_path / "abi.c"
-    src.write_text('#include "tripolar_hip.h"\n'
+    src.write_text('#include "tripolar_hip_test.h"\n'
                    + "typedef void (*fn)(void);\nstatic fn table[] = {" + ", ".join(f"(fn){n}" for n in names) + "};\n"
                    + "int main(void) { tpg_params p = {0}; (void)p; return sizeof(table) == 0 || TPG_NUM_ARRAYS != 20 || TPG_COMM_ID_BYTES != 128; }\n")
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),

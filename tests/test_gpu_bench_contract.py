@@ -24,49 +24,91 @@ def test_bench_prints_one_contract_line(gpu):
         assert isinstance(d[key], typ), (key, d[key])
     assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["unit"] == "cells/s" and d["dtype"] == "f64" and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert "merged" in d["config"]["workload"] and d["config"]["rows_per_rank"] == 1800
     assert "workload" in d["config"] and "model" not in d["config"]
     # value = cells of one step / step time
     assert abs(d["value"] - 3600 * 1800 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
-    r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.2 < r["frac"] < 1.0
-    assert r["algorithmic_bytes_per_launch"] == 73440000 and (r["traffic"] is None or r["traffic"] >= 0.95 * 73440000)
+    zb, pb = 73440000, 4 * 1808 * 83 * 128
+    r = d["roofline"]                                # the fill kernel the step launches (the product's default: one merged launch)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and "k_fill_merged" in r["kernel"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.1 < r["frac"] < 1.0
+    assert r["algorithmic_bytes_per_launch"] == zb + pb and (r["traffic"] is None or r["traffic"] >= 0.95 * (zb + pb))
+    assert abs(r["launch_ms"] - d["fill_ms"]) < 1e-12 and r["launch_ms"] < d["ms_per_step"]
+    f = d["roofline_fold"]                           # the fold alone (north_star's kernel), K launches in step context + copy ceiling
+    assert f["bound"] == "hbm" and "k_zipper_cols" in f["kernel"] and f["algorithmic_bytes_per_launch"] == zb
+    assert abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-12 and 0.2 < f["frac"] < 1.0
+    assert f["traffic"] is None or f["traffic"] >= 0.95 * zb
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "cells/s" and c["value"] > 1e5 and "oracle" in c["sample"]
     assert d["value"] > 100 * c["value"]            # sanity: the HIP path is the thing measured, not the oracle
     a = c["all_cores"]                               # single thread AND all cores, core count stated
     assert a["cores"] >= 1 and a["nproc"] >= a["cores"] and a["value"] > 0
-    # cold and warm zipper launch durations, and the same-shape copy ceiling beside them
+    # cold and warm fold launch durations, the same-shape copy ceiling, and the same states for the merged fill
     assert 0 < d["zipper_warm_ms"] <= d["zipper_cold_dirty_ms"] * 1.5 and d["zipper_cold_ms"] > 0 and d["zipper_copy_ceiling_ms"] > 0
-    assert r["copy_ceiling_ms"] == d["zipper_copy_ceiling_ms"]
+    assert f["copy_ceiling_ms"] == d["zipper_copy_ceiling_ms"]
+    assert d["fill_merged_cold_ms"] > d["zipper_cold_ms"] and d["fill_merged_warm_ms"] > 0
     assert d["config2_quarter_degree_build"]["cells_per_s"] > 1e9
+    f32 = d["float32"]                               # the reference tests both element types (test/runtests.jl:10)
+    assert f32["fold_algorithmic_bytes"] == zb // 2 and 0 < f32["fold_ms"] < d["zipper_cold_ms"] * 1.2
+    assert f32["fill_algorithmic_bytes"] == (zb + pb) // 2 and f32["build_cells_per_s"] > 1e9
     assert "prewarm_steps" not in d                  # exactly W warm-up steps
-    assert d["periodic_x_ms"] > 0 and d["exchange_ms"] is None and d["periodic_x"]["line_bytes"] == 3 * d["periodic_x"]["algorithmic_bytes"]
+    assert "exchange_ms" not in d and "periodic_x" not in d and "line_frac_of_hbm_peak" not in json.dumps(d)
     # config 5: the fills of one baroclinic step at 1/24 degree x 100 levels
     fs = d["fill_step"]
     assert "skipped" in fs or (fs["fill3d_us"] > 0 and fs["substep_fills_us"] > 0 and fs["substeps"] == 30
                                and abs(fs["total_us"] - fs["fill3d_us"] - fs["substep_fills_us"]) < 1e-6 and fs["fields_GB"] > 160)
 
 
-def test_bench_two_ranks_rehearsal(gpu):
-    """The N > 1 code path of bench.py (latitude bands, zipper on the north rank, seam exchange on a side stream beside the
-    build) as a FRESH child process: two ranks on this one GPU, seam messages host-staged over gloo (RCCL refuses two ranks on
-    one device; the RCCL leg itself is tests/test_gpu_exchange.py).  Timings of such a run mean nothing; the contract does."""
+def _two_rank_bench(extra):
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, TPG_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["config"]["global_size"] == [3600, 3600, 75] and d["config"]["parallelism"] == "latitude-bands x2"
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_rehearsal(gpu):
+    """The N > 1 code path of bench.py as a FRESH child process: two ranks on this one GPU, seam messages host-staged over gloo
+    (RCCL refuses two ranks on one device; the RCCL leg itself is tests/test_gpu_exchange.py).  Default = STRONG scaling =
+    BASELINE config 4's geometry (the 3600 x 1800 x 75 globe in N bands; N = 2 here: 900 rows each, the zipper on rank 1);
+    `--scaling weak` is the named alternative.  Timings of such a run mean nothing; the contract does."""
+    d = _two_rank_bench([])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["global_size"] == [3600, 1800, 75] and d["config"]["local_size"] == [3600, 900, 75]
+    assert d["config"]["rows_per_rank"] == 900 and d["config"]["parallelism"] == "latitude-bands x2" and "config 4" in d["config"]["workload"]
     assert isinstance(d["exchange_ms"], float) and d["exchange_ms"] > 0 and "gloo" in d["exchange_transport"]
-    assert d["seam_GBps_per_direction"] > 0 and d["overlap"] is not None
-    assert abs(d["value"] - 2 * 3600 * 1800 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["seam_GBps_per_direction"] > 0 and d["overlap"] is not None and 0.0 <= d["overlap_hidden_frac"] <= 1.0
+    assert d["exchange_over_build"] > 0 and d["fill_plus_exchange_ms"] >= d["exchange_ms"]
+    assert abs(d["value"] - 3600 * 1800 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]            # the globe is fixed: strong
+    assert d["precompute_cells_per_s"] > 0 and d["roofline"]["launch_ms"] > 0
     assert "cpu_baseline" not in d and "fill_step" not in d           # rank 0 at N = 1 only
+    w = _two_rank_bench(["--scaling", "weak"])
+    assert w["scaling"] == "weak" and w["config"]["global_size"] == [3600, 3600, 75] and w["config"]["local_size"] == [3600, 1800, 75]
+    assert abs(w["value"] - 2 * 3600 * 1800 / (w["ms_per_step"] * 1e-3)) <= 1e-6 * w["value"]
+
+
+def test_bench_deadline_fires_with_a_diagnostic(gpu):
+    """A stalled first exchange must end the job loudly: rank 1 of a two-rank rehearsal is told (TPG_BENCH_TEST_STALL_RANK) to sleep
+    instead of entering its first fill, so rank 0 blocks in the gloo exchange; with a 10 s deadline rank 0 prints the one-line JSON
+    diagnostic (rank, peers, phase) on stderr and the job exits non-zero -- no JSON line on stdout."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, TPG_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1", TPG_BENCH_TEST_STALL_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--deadline", "10"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith('{"metric"')]
+    diag = [json.loads(l[l.index("{"):]) for l in p.stderr.splitlines() if "bench_deadline_expired" in l]
+    assert diag, p.stderr[-3000:]
+    d0 = [d for d in diag if d["rank"] == 0][0]
+    assert d0["world"] == 2 and d0["peers"] == {"south": None, "north": 1} and "first seam exchange" in d0["phase"] and d0["deadline_s"] == 10

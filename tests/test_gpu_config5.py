@@ -25,7 +25,8 @@ SUBSTEPS = 30
 
 
 def _synthetic(osg, field, seed):
-    lib = osg._lib.lib()
+    from tools import testlib
+    lib = testlib.lib()
     rc = lib.tpg_fill_synthetic(field.data.data_ptr(), seed, 12345.0, field.Nx, field.Ny, field.Nz, field.Hx, field.Hy, field.Hz,
                                 osg._lib.ft_of(field.data.dtype), None)
     assert rc == 0

@@ -88,7 +88,7 @@ def test_pack_unpack_roundtrip_and_layout(osg, gpu):
             assert torch.equal(f, b)
 
 
-def test_config4_eight_bands_at_full_size(osg, gpu):
+def test_config4_eight_bands_at_full_size(osg, gpu, tlib):
     """BASELINE config 4 at its real geometry: the 1/10 degree grid (3600 x 1800 x 75, halo 4, Float64) as 8 latitude bands of
     ny = 225 rows, the four bench fields c / u / v / zeta, on ONE GPU with the 8 ranks emulated in this process (two-phase
     loop-back transport; the RCCL leg itself is tests/test_gpu_exchange.py).
@@ -108,7 +108,7 @@ def test_config4_eight_bands_at_full_size(osg, gpu):
     for fid, (xl, yl, sg) in enumerate(specs):
         loc = (osg.Face if xl else osg.Center, osg.Face if yl else osg.Center, osg.Center)
         f = osg.Field(loc, serial)
-        assert lib.tpg_fill_synthetic(f.data.data_ptr(), 0xC4 + fid, 12345.0, *size, *halo, 1, None) == 0
+        assert tlib.tpg_fill_synthetic(f.data.data_ptr(), 0xC4 + fid, 12345.0, *size, *halo, 1, None) == 0
         globs.append(f.data.clone())
         filled.append(f)
     osg.fill_halo_regions(filled)                                   # the serial reference fill
@@ -141,3 +141,121 @@ def test_config4_eight_bands_at_full_size(osg, gpu):
         jstart, jend = grid.jrange
         for f, ref in zip(fs, filled):
             assert torch.equal(f.data, ref.data[:, jstart - 1:jend + 2 * Hy]), (r, f.loc)
+
+
+class _PeerPeek:
+    """A PLAIN-CALLABLE transport (no post/wait, no cloning) for R ranks emulated in one process: at finish() time it copies,
+    batch by batch, straight out of the peer exchange's own send buffers.  Any sharing of message buffers between batches or
+    between plans that are in flight together shows up as wrong halos (the module-global buffer cache did that)."""
+
+    def __init__(self):
+        self.exchanges = {}                      # (tag, rank) -> PendingExchange
+
+    def endpoint(self, tag, me):
+        state = {"calls": 0}
+
+        def transport(plan, send, recv, group):
+            mine = self.exchanges[(tag, me)]
+            b = state["calls"] % len(mine.batches)
+            state["calls"] += 1
+            for m in plan:
+                peer = self.exchanges[(tag, m.peer)].batches[b][2]
+                recv[m.side].copy_(peer.send[1 - m.side])          # what the peer packed for the side that faces me
+        return transport
+
+
+def _band_fields(osg, grid, globs, specs, tdt, sent=SENT):
+    jstart, jend = grid.jrange
+    Hy = grid.Hy
+    fs = []
+    for (xl, yl, sg), g in zip(specs, globs):
+        loc = (osg.Face if xl else osg.Center, osg.Face if yl else osg.Center, osg.Center)
+        f = osg.Field(loc, grid)
+        slab = g[:, jstart - 1:jend + 2 * Hy].copy()
+        slab[:, :Hy] = sent; slab[:, Hy + (jend - jstart + 1):] = sent
+        f.data.copy_(torch.from_numpy(slab))
+        fs.append(f)
+    return fs
+
+
+def test_35_fields_through_a_plain_callable_transport(osg, oracle, gpu):
+    """more fields than one batch (TPG_MAX_FIELDS = 16): three batches, two of them of equal shape, every batch with its own
+    message buffers, all packed in begin() before any is delivered in finish()"""
+    size, halo, R = (24, 16, 2), (4, 4, 1), 2
+    (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
+    rng = np.random.default_rng(35)
+    specs = [(int(rng.integers(0, 2)), int(rng.integers(0, 2)), 0) for _ in range(35)]
+    specs = [(x, y, -1 if x != y else 1) for x, y, _ in specs]               # the default sign policy by location
+    globs = []
+    for _ in specs:
+        g = rng.uniform(-1, 1, (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx))
+        g[:, :Hy] = SENT; g[:, Hy + Ny:] = SENT
+        globs.append(g)
+    peek = _PeerPeek()
+    plans, ranks = [], []
+    for r in range(R):
+        grid = osg.TripolarGrid(osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=r), torch.float64, size=size, halo=halo)
+        fs = _band_fields(osg, grid, globs, specs, torch.float64)
+        plan = osg.halo_fill_plan(fs, exchange=peek.endpoint("a", r))
+        (_, _, pending), = plan._steps
+        assert len(pending.batches) == 3 and [len(b[0]) for b in pending.batches] == [16, 16, 3]
+        bufs = [b[2].send[side].data_ptr() for b in pending.batches for side in b[2].send]
+        assert len(set(bufs)) == len(bufs)                                      # no two batches share a message buffer
+        peek.exchanges[("a", r)] = pending
+        plans.append(plan); ranks.append((grid, fs))
+    for plan in plans:
+        plan.begin()
+    for plan in plans:
+        plan.finish()
+    torch.cuda.synchronize()
+    for (xl, yl, sg), g in zip(specs, globs):
+        oracle.fill_halo_regions(g, xl, yl, sg, size, halo)
+    for r, (grid, fs) in enumerate(ranks):
+        jstart, jend = grid.jrange
+        for k, (f, g) in enumerate(zip(fs, globs)):
+            assert np.array_equal(f.data.cpu().numpy(), g[:, jstart - 1:jend + 2 * Hy]), (r, k, f.loc)
+
+
+def test_two_plans_of_equal_geometry_in_flight_together(osg, oracle, gpu):
+    """two HaloFillPlans over different fields of the SAME geometry, begun back to back and only then finished: each plan owns
+    its message buffers, so the second pack cannot overwrite the first plan's posted message"""
+    size, halo, R = (32, 24, 3), (4, 4, 2), 3
+    (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
+    rng = np.random.default_rng(77)
+    sets = {}
+    for tag in ("a", "b"):
+        globs = []
+        for _ in SPECS:
+            g = rng.uniform(-1, 1, (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx))
+            g[:, :Hy] = SENT; g[:, Hy + Ny:] = SENT
+            globs.append(g)
+        sets[tag] = globs
+    peek = _PeerPeek()
+    plans = {"a": [], "b": []}
+    ranks = {"a": [], "b": []}
+    for r in range(R):
+        grid = osg.TripolarGrid(osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=r), torch.float64, size=size, halo=halo)
+        for tag in ("a", "b"):
+            fs = _band_fields(osg, grid, sets[tag], SPECS, torch.float64)
+            plan = osg.halo_fill_plan(fs, exchange=peek.endpoint(tag, r))
+            peek.exchanges[(tag, r)] = plan._steps[0][2]
+            plans[tag].append(plan); ranks[tag].append((grid, fs))
+    for r in range(R):
+        a, b = peek.exchanges[("a", r)].batches[0][2], peek.exchanges[("b", r)].batches[0][2]
+        assert not {t.data_ptr() for t in a.send.values()} & {t.data_ptr() for t in b.send.values()}
+    for tag in ("a", "b"):                      # begin A on every rank, begin B on every rank ...
+        for plan in plans[tag]:
+            plan.begin()
+    for tag in ("a", "b"):                      # ... and only then deliver
+        for plan in plans[tag]:
+            plan.finish()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="begin"):
+        plans["a"][1]._steps[0][2].finish()     # a second finish without begin is refused
+    for tag in ("a", "b"):
+        for (xl, yl, sg), g in zip(SPECS, sets[tag]):
+            oracle.fill_halo_regions(g, xl, yl, sg, size, halo)
+        for r, (grid, fs) in enumerate(ranks[tag]):
+            jstart, jend = grid.jrange
+            for f, g in zip(fs, sets[tag]):
+                assert np.array_equal(f.data.cpu().numpy(), g[:, jstart - 1:jend + 2 * Hy]), (tag, r, f.loc)

@@ -21,8 +21,15 @@ def test_rccl_seam_exchange_single_rank_loopback(gpu):
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["ok"] and d["single_rank_chain_rc"] == 0 and d["from_torch"] == [0, 1]
-    assert len(d["cases"]) == 6 and all(c["bit_exact"] for c in d["cases"])
+    assert len(d["cases"]) == 8 and all(c["bit_exact"] for c in d["cases"])
     assert {c["packed"] for c in d["cases"]} == {True, False}
+    assert [3600, 225, 75] in [c["size"] for c in d["cases"]]                       # BASELINE config 4's band geometry (ny = 225)
+    # the whole band fill through ONE C call (tpg_fill_halo_regions_distributed_peers): a middle band and the zipper band
+    assert [c["band"] for c in d["distributed_fill"]] == ["middle", "north"] and all(c["bit_exact"] for c in d["distributed_fill"])
+    assert d["two_streams_own_buffers_bit_exact"] is True
+    # a capturing stream is refused instead of stalling, and the capture survives the refusal
+    f = d["capture_fence"]
+    assert f["rc"] == -5 and "captured" in f["message"] and f["periodic_rc_in_capture"] == 0 and f["replay_bit_exact"]
 
 
 def test_exchange_argument_errors(osg, gpu):

@@ -9,12 +9,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_acos_device_bits(osg, oracle, gpu):
+def test_acos_device_bits(osg, oracle, gpu, tlib):
     x = np.concatenate([np.linspace(-1, 1, 4001), np.random.default_rng(1).uniform(-1, 1, 20000), [1e-20, -1e-20, 0.5, -0.5, 1.5]])
     d = torch.from_numpy(x).to(gpu)
     y = torch.empty_like(d)
     rare = torch.zeros(x.size, dtype=torch.int32, device=gpu)
-    assert osg._lib.lib().tpg_math_probe(10, d.data_ptr(), y.data_ptr(), rare.data_ptr(), x.size, None) == 0
+    assert tlib.tpg_math_probe(10, d.data_ptr(), y.data_ptr(), rare.data_ptr(), x.size, None) == 0
     torch.cuda.synchronize()
     assert np.array_equal(y.cpu().numpy(), oracle.math_probe("acos", x), equal_nan=True)
 

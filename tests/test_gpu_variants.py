@@ -1,6 +1,7 @@
 """Every kernel variant kept in the library (the simple thread-per-cell build kernel and the LDS-tile default; the
 zipper's row-item and column-item forms) must produce identical bits: they differ only in how the same arithmetic is
-scheduled.  The TPG_* knobs are read once into an immutable record; tpg_reload_config() publishes a new one."""
+scheduled.  The TPG_* knobs exist in the TEST library only (tools/libtripolar_hip_test.so; the product library reads no
+environment variable): they are read once into an immutable record; tpg_reload_config() publishes a new one."""
 import os
 
 import numpy as np
@@ -12,7 +13,7 @@ KNOBS = ("TPG_CELLS_VARIANT", "TPG_BUILD_NT", "TPG_ZIPPER_VARIANT")
 
 
 @pytest.fixture
-def knob(osg):
+def knob(osg, via_testlib):
     saved = {k: os.environ.get(k) for k in KNOBS}
     yield os.environ
     for k, v in saved.items():
@@ -20,7 +21,7 @@ def knob(osg):
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
-    osg._lib.lib().tpg_reload_config()
+    via_testlib.tpg_reload_config()
 
 
 @pytest.mark.parametrize("kw", [dict(size=(250, 100, 1)),
@@ -76,3 +77,25 @@ def test_knobs_are_read_once(osg, gpu, knob):
     # ... which the copy probe requires (it refuses geometries without a column kernel, not the knob)
     assert lib.tpg_zipper_copy_probe(osg._lib.ptr_table([d]), 1, (C.c_int8 * 1)(0), 16, 8, 1, 4, 4, 1, 1, None, None, None) == 0
     torch.cuda.synchronize()
+
+
+def test_product_library_ignores_the_knobs(osg, gpu):
+    """libtripolar_hip.so reads no environment variable: with TPG_FILL_MERGED=0 / TPG_ZIPPER_VARIANT=0 exported it still exports no
+    reload hook and produces the same fill (the default kernels)"""
+    lib = osg._lib.lib()
+    assert not hasattr(lib, "tpg_reload_config")
+    saved = {k: os.environ.get(k) for k in ("TPG_ZIPPER_VARIANT", "TPG_FILL_MERGED", "TPG_FILL_FUSED")}
+    try:
+        grid = osg.TripolarGrid(osg.GPU(0), torch.float64, size=(64, 40, 2), halo=(4, 4, 2))
+        u = osg.XFaceField(grid)
+        u.data.copy_(torch.rand_like(u.data))
+        a = u.data.clone()
+        osg.fill_halo_regions([u])
+        want = u.data.clone()
+        os.environ.update(TPG_ZIPPER_VARIANT="0", TPG_FILL_MERGED="0", TPG_FILL_FUSED="0")
+        u.data.copy_(a)
+        osg.fill_halo_regions([u])
+        assert torch.equal(u.data, want)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)

@@ -90,15 +90,16 @@ class _Knob:
 
 
 @pytest.fixture
-def fused_knob(osg):
+def fused_knob(osg, via_testlib):
+    """the knobs live in the test library only: the package's calls go through it for the duration of the test"""
     saved = {k: os.environ.get(k) for k in ("TPG_FILL_FUSED", "TPG_FILL_MERGED")}
-    yield _Knob(osg._lib.lib())
+    yield _Knob(via_testlib)
     for k, v in saved.items():
         if v is None:
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
-    osg._lib.lib().tpg_reload_config()
+    via_testlib.tpg_reload_config()
 
 
 @pytest.mark.parametrize("fused,merged", [("0", "0"), ("1", "0"), ("0", "1")], ids=["two-launch", "fused", "merged"])
@@ -197,9 +198,9 @@ def test_unaligned_base_pointer_takes_the_scalar_kernel(osg, oracle, gpu):
     assert np.array_equal(view.cpu().numpy().reshape(shape), h)
 
 
-def test_synthetic_fill_matches_host_twin(osg, gpu):
+def test_synthetic_fill_matches_host_twin(osg, gpu, tlib):
     size, halo = (24, 10, 3), (4, 4, 2)
-    lib = osg._lib.lib()
+    lib = tlib
     for dt, tdt, ft in ((np.float64, torch.float64, 1), (np.float32, torch.float32, 0)):
         d = torch.empty((3 + 4, 10 + 8, 24 + 8), dtype=tdt, device=gpu)
         assert lib.tpg_fill_synthetic(d.data_ptr(), 0x5EED + 1, 12345.0, *size, *halo, ft, None) == 0
@@ -207,7 +208,7 @@ def test_synthetic_fill_matches_host_twin(osg, gpu):
         assert np.array_equal(d.cpu().numpy(), synthetic_field(0x5EED + 1, 12345.0, size, halo, dt))
 
 
-def test_config3_tenth_degree_75_levels(osg, oracle, gpu):
+def test_config3_tenth_degree_75_levels(osg, oracle, gpu, tlib):
     """BASELINE config 3: (3600,1800,75), halo 4, Float64, fields c(CC,+1) u(FC,-1) v(CF,-1) zeta(FF,+1),
     splitmix64 interior / sentinel halos.  Full-size checks:
       * bit-exact parity of every row the fold can touch (rows Ny-Hy..Ny+Hy, all levels) against the
@@ -223,7 +224,7 @@ def test_config3_tenth_degree_75_levels(osg, oracle, gpu):
     fields = []
     for fid, _ in enumerate(specs):
         d = torch.empty(shape, dtype=torch.float64, device=gpu)
-        assert lib.tpg_fill_synthetic(d.data_ptr(), 0x5EED + fid, 12345.0, *size, *halo, 1, None) == 0
+        assert tlib.tpg_fill_synthetic(d.data_ptr(), 0x5EED + fid, 12345.0, *size, *halo, 1, None) == 0
         fields.append(d)
     top = slice(Ny - 1, Ny + 2 * Hy)            # parent rows of logical rows Ny-Hy .. Ny+Hy
     before = [f[:, top].cpu().numpy() for f in fields]

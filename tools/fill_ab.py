@@ -7,10 +7,11 @@ import ctypes as C, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from orthogonalsphericalshellgrids.jl_amd import _lib
+from tools import testlib           # knobs, synthetic fill, copy probe: the test library (same kernels)
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 torch.cuda.set_device(0); dev = torch.device("cuda", 0)
-lib = _lib.lib()
+lib = testlib.lib()
 flush = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
 ev = lambda: torch.cuda.Event(enable_timing=True)
 

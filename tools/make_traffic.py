@@ -20,7 +20,10 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         m = re.search(r"(k_[a-z_]+)", r["Kernel_Name"])
-        acc[m.group(1) if m else "?"].append(float(r["Counter_Value"]))
+        name = m.group(1) if m else "?"
+        if name == "k_zipper_cols" and "true>" in r["Kernel_Name"].split("k_zipper_cols")[1][:24]:
+            name = "k_zipper_cols_copy_probe"
+        acc[name].append(float(r["Counter_Value"]))
     return {k: sum(v[1:]) / max(1, len(v[1:])) * 1024.0 for k, v in acc.items()}
 
 
@@ -30,14 +33,14 @@ def main():
     for k in fetch:
         kernels[k] = {"fetch_bytes_raw": fetch[k], "fetch_bytes_corrected": 2 * fetch[k], "write_bytes": write.get(k, 0.0),
                       "hbm_bytes_per_launch": 2 * fetch[k] + write.get(k, 0.0)}
-    src = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "csrc", "tpg_zipper.hip")
+    src = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "csrc", "tpg_zipper_kernels.hpp")
     out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc.sh) over `bench.py --no-aux --no-fill-step "
                       f"--steps 5 --warmup 1`: {os.path.relpath(sys.argv[1], ROOT)}, {os.path.relpath(sys.argv[2], ROOT)}; per-launch averages "
                       "(first launch dropped). Counter unit = KiB; FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B, "
                       "MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as read.",
            # bench.py reports `roofline.traffic` only while the kernel source is the one these counters were taken on
-           "zipper_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
-           "kernels": kernels, "k_zipper_cols_bytes_per_launch": kernels["k_zipper_cols"]["hbm_bytes_per_launch"]}
+           "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
+           "kernels": kernels}
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     for k, v in kernels.items():

@@ -35,7 +35,8 @@ def main():
     rng = np.random.default_rng(5)
     for (Nx, Ny, Nz), (Hx, Hy, Hz), nf, dt, tdt in (((48, 40, 3), (4, 4, 2), 3, np.float64, torch.float64),
                                                    ((20, 12, 2), (3, 2, 1), 2, np.float32, torch.float32),
-                                                   ((3600, 64, 75), (4, 4, 4), 4, np.float64, torch.float64)):
+                                                   ((3600, 64, 75), (4, 4, 4), 4, np.float64, torch.float64),
+                                                   ((3600, 225, 75), (4, 4, 4), 4, np.float64, torch.float64)):     # BASELINE config 4's band
         shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
         ft = 1 if dt == np.float64 else 0
         for packed in (True, False):
@@ -71,6 +72,85 @@ def main():
             steady = (time.perf_counter() - t0) / 5 * 1e3
             out["cases"].append({"size": [Nx, Ny, Nz], "nfields": nf, "packed": packed, "bit_exact": good, "first_call_ms": round(ms, 3),
                                  "steady_call_ms": round(steady, 3)})
+    # ---- tpg_fill_halo_regions_distributed_peers: the whole fill of a band in ONE call (zipper / periodic x / seams) ----------
+    (Nx, Ny, Nz), (Hx, Hy, Hz) = (48, 40, 3), (4, 4, 2)
+    shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
+    specs = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]
+    xl = (C.c_int8 * 4)(*[s_[0] for s_ in specs]); yl = (C.c_int8 * 4)(*[s_[1] for s_ in specs]); sg = (C.c_int32 * 4)(*[s_[2] for s_ in specs])
+    nbuf = lib.tpg_y_halo_buffer_elems(4, Nx, Nz, Hx, Hy, Hz)
+    bufs = [torch.empty(nbuf, dtype=torch.float64, device=dev) for _ in range(4)]
+    stream = _lib.current_stream_ptr(dev)
+    dcases = []
+    # (a) a middle band: no zipper, both seams (peers = this rank): periodic x, then south halo <- own north interior rows etc.
+    # (b) the north band: zipper + periodic x, then the south seam only (south halo <- own south interior rows: the one send pairs the one recv)
+    for label, south, north, zipper in (("middle", 0, 0, 0), ("north", 0, -1, 1)):
+        hosts = [rng.uniform(-1, 1, shape) for _ in specs]
+        devs = [torch.from_numpy(h).to(dev) for h in hosts]
+        # expected: the product's own LOCAL fill (bit-exact against the oracle in tests/test_gpu_zipper.py) + the loop-back row moves
+        refs = [d.clone() for d in devs]
+        _lib.check(lib.tpg_fill_halo_regions(_lib.ptr_table(refs), 4, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, zipper, 1, stream))
+        rc = lib.tpg_fill_halo_regions_distributed_peers(comm.handle, south, north, zipper, _lib.ptr_table(devs), 4, xl, yl, sg,
+                                                         bufs[0].data_ptr(), bufs[1].data_ptr() if north >= 0 else None,
+                                                         bufs[2].data_ptr(), bufs[3].data_ptr() if north >= 0 else None,
+                                                         Nx, Ny, Nz, Hx, Hy, Hz, 1, stream)
+        torch.cuda.synchronize()
+        good = rc == 0
+        for r, d in zip(refs, devs):
+            want = r.clone()
+            if north >= 0:
+                want[:, :Hy] = r[:, Ny:Ny + Hy]; want[:, Ny + Hy:] = r[:, Hy:2 * Hy]
+            else:
+                want[:, :Hy] = r[:, Hy:2 * Hy]
+            good = good and bool(torch.equal(d, want))
+        dcases.append({"band": label, "rc": rc, "bit_exact": bool(good)})
+        out["ok"] = out["ok"] and good
+    out["distributed_fill"] = dcases
+
+    # ---- two exchanges of EQUAL geometry in flight on two streams, each with its own message buffers (seam-buffer ownership) ----
+    (Nx, Ny, Nz), (Hx, Hy, Hz) = (3600, 64, 8), (4, 4, 4)
+    shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
+    nbuf = lib.tpg_y_halo_buffer_elems(2, Nx, Nz, Hx, Hy, Hz)
+    sets = []
+    for q in range(2):
+        hosts = [rng.uniform(-1, 1, shape) for _ in range(2)]
+        sets.append((hosts, [torch.from_numpy(h).to(dev) for h in hosts], [torch.empty(nbuf, dtype=torch.float64, device=dev) for _ in range(4)],
+                     torch.cuda.Stream(dev)))
+    torch.cuda.synchronize()
+    rcs = []
+    for rep in range(3):
+        for hosts, devs, bb, st in sets:
+            rcs.append(lib.tpg_halo_exchange_y_peers(comm.handle, 0, 0, _lib.ptr_table(devs), 2, *[b.data_ptr() for b in bb],
+                                                     Nx, Ny, Nz, Hx, Hy, Hz, 1, C.c_void_p(st.cuda_stream)))
+    torch.cuda.synchronize()
+    good = all(r == 0 for r in rcs)
+    for hosts, devs, bb, st in sets:
+        for h, d in zip(hosts, devs):
+            want = h.copy()
+            want[:, :Hy] = h[:, Ny:Ny + Hy]; want[:, Ny + Hy:] = h[:, Hy:2 * Hy]
+            good = good and np.array_equal(d.cpu().numpy(), want)
+    out["two_streams_own_buffers_bit_exact"] = bool(good)
+    out["ok"] = out["ok"] and good
+
+    # ---- the capture fence: a capturing stream is refused (TPG_ERR_UNSUPPORTED), the capture itself stays valid -----------------
+    d2 = torch.rand((4, 20, 24), dtype=torch.float64, device=dev)
+    before = d2.clone()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream())
+    bb = [torch.empty(lib.tpg_y_halo_buffer_elems(1, 16, 2, 4, 4, 1), dtype=torch.float64, device=dev) for _ in range(4)]
+    with torch.cuda.stream(side), torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+        sp = C.c_void_p(side.cuda_stream)
+        rc_fence = lib.tpg_halo_exchange_y_peers(comm.handle, 0, 0, _lib.ptr_table([d2]), 1, *[b.data_ptr() for b in bb], 16, 12, 2, 4, 4, 1, 1, sp)
+        msg = lib.tpg_last_error().decode()
+        rc_per = lib.tpg_periodic_x_fill(_lib.ptr_table([d2]), 1, 16, 12, 2, 4, 4, 1, 1, sp)        # a capturable call after the refusal
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    want = before.clone()
+    want[:, :, :4] = before[:, :, 16:20]; want[:, :, 20:] = before[:, :, 4:8]
+    out["capture_fence"] = {"rc": rc_fence, "message": msg, "periodic_rc_in_capture": rc_per, "replay_bit_exact": bool(torch.equal(d2, want))}
+    out["ok"] = out["ok"] and rc_fence == -5 and rc_per == 0 and out["capture_fence"]["replay_bit_exact"]
+
     # the chain rule: a one-rank chain has no seam
     d = torch.zeros((1, 12, 12), dtype=torch.float64, device=dev)
     out["single_rank_chain_rc"] = lib.tpg_halo_exchange_y(comm.handle, 0, 1, _lib.ptr_table([d]), 1, None, None, None, None, 4, 4, 1, 4, 4, 0, 1, None)

@@ -6,11 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import orthogonalsphericalshellgrids.jl_amd as osg
 from orthogonalsphericalshellgrids.jl_amd import _lib
+from tools import testlib           # knobs, synthetic fill, copy probe: the test library (same kernels)
 from oracle import oracle
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
-lib = _lib.lib()
+lib = testlib.lib()
 bad = 0
 for t in range(trials):
     Nx = 2 * int(rng.integers(1, 150)); Ny = int(rng.integers(1, 40)); Nz = int(rng.integers(1, 5))

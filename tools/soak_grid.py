@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import orthogonalsphericalshellgrids.jl_amd as osg
 from oracle import oracle
+from tools import testlib
+testlib.active().__enter__()          # the TPG_* knobs live in the test library: route the package through it
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
@@ -17,7 +19,7 @@ for t in range(trials):
               first_pole_longitude=float(np.round(rng.uniform(-200, 380), int(rng.integers(0, 6)))),
               southernmost_latitude=float(np.round(rng.uniform(-88, 15), int(rng.integers(0, 6)))), radius=float(rng.choice([1.0, 6371e3, 3389.5e3])))
     dtype, tdt = ((np.float64, torch.float64), (np.float32, torch.float32))[t % 5 == 0]
-    os.environ["TPG_CELLS_VARIANT"] = "3" if t % 3 else "0"; osg._lib.lib().tpg_reload_config()
+    os.environ["TPG_CELLS_VARIANT"] = "3" if t % 3 else "0"; testlib.lib().tpg_reload_config()
     ref = oracle.build_grid(dtype=dtype, **kw)
     g = osg.TripolarGrid(osg.GPU(0), tdt, **kw)
     for name, r in ref.items():

@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""Per-kernel duration summary of a rocprofv3 --kernel-trace CSV of bench.py, restricted to the launches that belong to
-bench STEPS (build -> zipper -> periodic x): the plain `--stats` table also averages the auxiliary launches of the same
-kernels (cold / warm probes, the config-5 fill_step), which have other sizes and cache states.
-A step launch is recognised by its neighbours in the trace: k_tables, k_cells_tile, k_halos, k_zipper_cols, k_periodic_x_vec
-in this order.  usage: tools/trace_summary.py <bench_kernel_trace.csv> [out.csv]"""
+"""Per-kernel duration summary of a rocprofv3 --kernel-trace CSV of bench.py (N = 1), restricted to the launches that belong
+to bench STEPS: the plain `--stats` table also averages the auxiliary launches of the same kernels (cold / warm probes, the
+Float32 and config-5 fills), which have other sizes and cache states.  Two launch sequences are recognised by their
+neighbours in the trace:
+  step       k_tables, k_cells_tile, k_halos, k_fill_merged                      (the timed steps and the instrumented pass)
+  fold pass  k_tables, k_cells_tile, k_halos, k_zipper_cols, k_periodic_x_vec    (the pass behind `roofline_fold`)
+A `step` whose kernels follow each other within 5 us is a TIMED step (the instrumented pass has stream markers between
+its phases, ~10 us each); only those enter the `timed_step` rows, which are the figures to compare with `roofline`.
+usage: tools/trace_summary.py <bench_kernel_trace.csv> [out.csv]"""
 import csv
 import re
 import statistics
 import sys
 
-ORDER = ["k_tables", "k_cells_tile", "k_halos", "k_zipper_cols", "k_periodic_x_vec"]
+STEP = ["k_tables", "k_cells_tile", "k_halos", "k_fill_merged"]
+FOLD = ["k_tables", "k_cells_tile", "k_halos", "k_zipper_cols", "k_periodic_x_vec"]
 
 
 def short(name):
@@ -20,23 +25,30 @@ def short(name):
 def main():
     rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
     names = [short(r["Kernel_Name"]) for r in rows]
-    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
-    acc = {k: [] for k in ORDER}
-    gaps = []
+    t0 = [int(r["Start_Timestamp"]) for r in rows]
+    t1 = [int(r["End_Timestamp"]) for r in rows]
+    dur = [(b - a) / 1e3 for a, b in zip(t0, t1)]
+    acc = {"timed_step": {k: [] for k in STEP}, "instrumented_step": {k: [] for k in STEP}, "fold_pass": {k: [] for k in FOLD}}
     i = 0
-    while i + len(ORDER) <= len(rows):
-        if names[i:i + len(ORDER)] == ORDER and "true>" not in rows[i + 3]["Kernel_Name"].split("k_zipper_cols")[1][:24]:
-            for k, d in zip(ORDER, dur[i:i + len(ORDER)]):
-                acc[k].append(d)
-            gaps.append((int(rows[i + 4]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3 - sum(dur[i:i + 5]))
-            i += len(ORDER)
+    while i < len(rows):
+        if names[i:i + len(FOLD)] == FOLD and "true>" not in rows[i + 3]["Kernel_Name"].split("k_zipper_cols")[1][:24]:
+            for k, d in zip(FOLD, dur[i:i + len(FOLD)]):
+                acc["fold_pass"][k].append(d)
+            i += len(FOLD)
+        elif names[i:i + len(STEP)] == STEP:
+            gaps = [(t0[i + j + 1] - t1[i + j]) / 1e3 for j in range(len(STEP) - 1)]
+            kind = "timed_step" if max(gaps) < 5.0 else "instrumented_step"
+            for k, d in zip(STEP, dur[i:i + len(STEP)]):
+                acc[kind][k].append(d)
+            i += len(STEP)
         else:
             i += 1
-    out = [("kernel", "step_launches", "avg_us", "median_us", "min_us", "max_us")]
-    for k in ORDER:
-        d = acc[k]
-        out.append((k, len(d), round(statistics.mean(d), 3), round(statistics.median(d), 3), round(min(d), 3), round(max(d), 3)))
-    out.append(("(gaps between the 5 kernels of a step)", len(gaps), round(statistics.mean(gaps), 3), round(statistics.median(gaps), 3), round(min(gaps), 3), round(max(gaps), 3)))
+    out = [("sequence", "kernel", "launches", "avg_us", "median_us", "min_us", "max_us")]
+    for kind, order in (("timed_step", STEP), ("instrumented_step", STEP), ("fold_pass", FOLD)):
+        for k in order:
+            d = acc[kind][k]
+            if d:
+                out.append((kind, k, len(d), round(statistics.mean(d), 3), round(statistics.median(d), 3), round(min(d), 3), round(max(d), 3)))
     w = csv.writer(open(sys.argv[2], "w", newline="") if len(sys.argv) > 2 else sys.stdout)
     w.writerows(out)
 

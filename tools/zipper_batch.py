@@ -4,9 +4,10 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from orthogonalsphericalshellgrids.jl_amd import _lib
+from tools import testlib           # knobs, synthetic fill, copy probe: the test library (same kernels)
 NX, NY, NZ, H = 3600, 1800, 75, 4
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
-lib = _lib.lib()
+lib = testlib.lib()
 shape = (NZ + 2 * H, NY + 2 * H, NX + 2 * H)
 NF = 16
 fields = []
