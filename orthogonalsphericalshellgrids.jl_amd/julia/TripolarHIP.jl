@@ -9,13 +9,13 @@
 # reference itself does not spell out (the south/north halo launcher) are marked [recalled].
 #
 # No CUDA.jl, no KernelAbstractions / AMDGPU.jl code generation: device memory is reached through raw pointers.
-# Three hooks adapt it to the array backend in use: `device_pointer`, `current_stream`, `device_zeros`.
+# Three hooks adapt it to the array backend in use: `device_pointer`, `current_stream`, `device_array`.
 module TripolarHIP
 
 export TripolarGrid, ZipperBoundaryCondition           # src/OrthogonalSphericalShellGrids.jl:4
 
 using Oceananigans
-using Oceananigans.Architectures: AbstractArchitecture, architecture, child_architecture, on_architecture
+using Oceananigans.Architectures: AbstractArchitecture, architecture, child_architecture, on_architecture, array_type
 using Oceananigans.Grids: R_Earth, Center, Face, Periodic, Bounded, RightConnected, FullyConnected,
                           OrthogonalSphericalShellGrid, generate_coordinate, halo_size, topology, cpu_face_constructor_z
 using Oceananigans.ImmersedBoundaries: ImmersedBoundaryGrid
@@ -27,6 +27,7 @@ using Oceananigans.DistributedComputations: Distributed, local_size, ranks, conc
                                             inject_halo_communication_boundary_conditions
 using OffsetArrays
 using Adapt
+import MPI                                   # a declared dependency of the reference (Project.toml:9): ferries the 128-byte RCCL id
 
 import Oceananigans.BoundaryConditions: bc_str, apply_y_north_bc!, regularize_field_boundary_conditions
 import Oceananigans.Fields: Field, validate_boundary_condition_location
@@ -69,7 +70,10 @@ end
 # backend hooks -------------------------------------------------------------------------------------------------------
 device_pointer(a) = Ptr{Cvoid}(UInt(pointer(parent(a))))         # raw HBM address of the parent array
 current_stream() = C_NULL                                         # hipStream_t of the task; NULL = default stream
-device_zeros(arch, FT, dims...) = on_architecture(arch, zeros(FT, dims...))   # a device array (HBM) of that shape
+# An UNINITIALISED device array (HBM) of that shape: tpg_build_grid overwrites every element of the 20 arrays, halos included,
+# so nothing is zeroed on the host and nothing crosses PCIe.  `array_type(arch)` is Oceananigans' own arch -> array-type map
+# [recalled: Oceananigans.Architectures.array_type, Array for CPU(), the device array type for GPU()].
+device_array(arch, FT, dims...) = array_type(child_architecture(arch)){FT}(undef, dims...)
 
 # ---------------------------------------------------------------------------------------------------------------------
 # 2. Tripolar mapping record, grid aliases            src/tripolar_grid.jl:6-17,371; distributed_tripolar_grid.jl:12-15
@@ -102,9 +106,9 @@ function build_band(arch, FT, size, halo, southernmost_latitude, radius, z, nort
     ny = jend - jstart + 1
     p = Ref(TpgParams(Nλ, Nφ, Nz, Hλ, Hφ, Hz, southernmost_latitude, north_poles_latitude, first_pole_longitude,
                       radius, ft_code(FT), jstart, jend, 0))
-    arrays = [device_zeros(arch, FT, Nλ + 2Hλ, ny + 2Hφ) for _ in 1:20]
+    arrays = [device_array(arch, FT, Nλ + 2Hλ, ny + 2Hφ) for _ in 1:20]
     nbytes = ccall((:tpg_build_grid_workspace_bytes, libtripolar), Csize_t, (Ref{TpgParams},), p)
-    workspace = device_zeros(arch, UInt8, Int(nbytes))
+    workspace = device_array(arch, UInt8, Int(nbytes))
     ptrs = Ptr{Cvoid}[device_pointer(a) for a in arrays]
     GC.@preserve arrays workspace begin
         check(ccall((:tpg_build_grid, libtripolar), Cint,
@@ -267,98 +271,7 @@ function Field((LX, LY, LZ)::Tuple, grid::DTRG, data, old_bcs, indices::Tuple, o
 end
 
 # ---------------------------------------------------------------------------------------------------------------------
-# 5. The halo-fill hook                                                 src/zipper_boundary_condition.jl:140-155
-# ---------------------------------------------------------------------------------------------------------------------
-# The reference's `_fill_north_halo!(i, k, grid, c, bc::ZBC, loc, args...)` is a per-thread function inlined into
-# Oceananigans' south/north halo kernel; a ccall cannot live there.  The interception point is one level up: the method of
-# the south/north launcher whose north condition is a ZBC ([recalled] `fill_south_and_north_halo!(c, south_bc, north_bc,
-# size, offset, loc, arch, grid, args...)` in Oceananigans 0.95-0.99; a tuple `c` is the tupled fill).
-loc_code(::Center) = Int8(0);  loc_code(::Type{Center}) = Int8(0)
-loc_code(::Face)   = Int8(1);  loc_code(::Type{Face})   = Int8(1)
-
-# (Nz, Hz) of ONE field from its own parent and z-location: a reduced field (LZ = Nothing, e.g. bottom_height at
-# (Center, Center, Nothing), test/test_zipper_boundary_conditions.jl:47-54) has one level and no z halo; a z-Face field
-# has Nz + 1 levels.  The grid's Nz / Hz are NOT used: indexing a 1-level parent with them would write out of bounds.
-function field_levels(c, loc, grid)
-    LZ = loc[3]
-    (LZ === Nothing || LZ isa Nothing) && return 1, 0
-    Hz = halo_size(grid)[3]
-    nlev = size(parent(c), 3)
-    return nlev - 2Hz, Hz                              # Center: Nz, Face (Bounded z): Nz + 1
-end
-
-zipper_sign(bc::ZBC) = Int32(bc.condition)
-
-# one C call per group of fields that share (element type, Nz, Hz): a tupled fill mixes 3-D and reduced fields
-function zipper_groups(fields, locs, grid)
-    groups = Dict{Tuple{DataType, Int, Int}, Vector{Int}}()
-    for (n, (c, loc)) in enumerate(zip(fields, locs))
-        Nz, Hz = field_levels(c, loc, grid)
-        push!(get!(groups, (eltype(parent(c)), Nz, Hz), Int[]), n)
-    end
-    return groups
-end
-
-"""
-    zipper_fill!(fields, bcs, locs, grid; periodic_x = false)
-
-`fold_north_*!` for every (i, k) of every field (src/zipper_boundary_condition.jl:70-155), one batched launch per
-geometry group; with `periodic_x = true` the whole `fill_halo_regions!` order zipper -> periodic west/east (pinned by
-test/test_zipper_boundary_conditions.jl:42-45; small 2-D fields take one fused launch inside the library).
-"""
-function zipper_fill!(fields, bcs, locs, grid; periodic_x::Bool = false)
-    Nx, Ny, _ = size(grid)
-    Hx, Hy, _ = halo_size(grid)
-    for ((FT, Nz, Hz), idx) in zipper_groups(fields, locs, grid)
-        fs   = [fields[n] for n in idx]
-        ptrs = Ptr{Cvoid}[device_pointer(f) for f in fs]
-        xloc = Int8[loc_code(locs[n][1]) for n in idx]
-        yloc = Int8[loc_code(locs[n][2]) for n in idx]
-        sgn  = Int32[zipper_sign(bcs[n]) for n in idx]
-        GC.@preserve fs begin
-            status = periodic_x ?
-                ccall((:tpg_fill_halo_regions, libtripolar), Cint,
-                      (Ptr{Ptr{Cvoid}}, Cint, Ptr{Int8}, Ptr{Int8}, Ptr{Int32},
-                       Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
-                      ptrs, length(fs), xloc, yloc, sgn, Nx, Ny, Nz, Hx, Hy, Hz, 1, ft_code(FT), current_stream()) :
-                ccall((:tpg_zipper_fill, libtripolar), Cint,
-                      (Ptr{Ptr{Cvoid}}, Cint, Ptr{Int8}, Ptr{Int8}, Ptr{Int32},
-                       Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
-                      ptrs, length(fs), xloc, yloc, sgn, Nx, Ny, Nz, Hx, Hy, Hz, 1, Nz, ft_code(FT), current_stream())
-            check(status)
-        end
-    end
-    return nothing
-end
-
-# The launcher's name is Oceananigans-internal and version dependent: the methods are added only where it exists, so that the
-# rest of the module (grid construction, metadata, exchange, geometry) loads on any version; `zipper_fill!` stays callable.
-@static if isdefined(Oceananigans.BoundaryConditions, :fill_south_and_north_halo!)
-
-import Oceananigans.BoundaryConditions: fill_south_and_north_halo!
-
-# single field: what fill_halo_regions!(field) reaches
-function fill_south_and_north_halo!(c, south_bc, north_bc::ZBC, size, offset, loc, arch, grid::Union{TRG, DTRG}, args...; kwargs...)
-    # the south side stays Oceananigans' (the reference's own fills leave it `nothing`, src/tripolar_grid.jl:148)
-    isnothing(south_bc) || Oceananigans.BoundaryConditions.fill_south_halo!(c, south_bc, size, offset, loc, arch, grid, args...; kwargs...)   # [recalled]
-    zipper_fill!((c,), (north_bc,), (loc,), grid)
-    return nothing
-end
-
-# tupled fill: fill_halo_regions!((u, v, c, ...)) hands tuples of data, conditions and locations
-function fill_south_and_north_halo!(c::NTuple, south_bc, north_bc::NTuple{N, <:ZBC}, size, offset, loc, arch,
-                                    grid::Union{TRG, DTRG}, args...; kwargs...) where N
-    for n in 1:N
-        isnothing(south_bc[n]) || Oceananigans.BoundaryConditions.fill_south_halo!(c[n], south_bc[n], size, offset, loc[n], arch, grid, args...; kwargs...)   # [recalled]
-    end
-    zipper_fill!(c, north_bc, loc, grid)
-    return nothing
-end
-
-end # @static if: launcher present
-
-# ---------------------------------------------------------------------------------------------------------------------
-# 6. Latitude-band seam exchange over RCCL                         src/distributed_tripolar_grid.jl:171,195 (transport)
+# 5. Latitude-band seam communicator (RCCL through the C ABI)          src/distributed_tripolar_grid.jl:171,195 (transport)
 # ---------------------------------------------------------------------------------------------------------------------
 mutable struct SeamComm
     handle::Ptr{Cvoid}
@@ -381,18 +294,200 @@ end
 
 destroy!(c::SeamComm) = (check(ccall((:tpg_comm_destroy, libtripolar), Cint, (Ptr{Cvoid},), c.handle)); c.handle = C_NULL; nothing)
 
+# One communicator per Distributed architecture, created at the first distributed fill: every rank first reports whether it can
+# bind librccl (tpg_comm_available: no collective call) and the ranks agree BEFORE the collective ncclCommInitRank; the 128-byte
+# id travels over the architecture's own MPI communicator (`arch.communicator`, `MPI.Allreduce` / `MPI.Bcast!` [recalled]).
+const SEAM_COMMS = IdDict{Any, SeamComm}()
+function seam_comm(arch::Distributed)
+    get!(SEAM_COMMS, arch) do
+        ok = ccall((:tpg_comm_available, libtripolar), Cint, ()) == 0 ? 1 : 0
+        MPI.Allreduce(ok, MPI.MIN, arch.communicator) == 1 || error("librccl cannot be bound on every rank: no seam communicator")
+        id = arch.local_rank == 0 ? comm_unique_id() : zeros(UInt8, 128)
+        MPI.Bcast!(id, 0, arch.communicator)
+        SeamComm(id, arch.local_rank, ranks(arch.partition)[2])
+    end
+end
+
+y_halo_buffer_elems(nfields, grid, Nz, Hz) =
+    Int(ccall((:tpg_y_halo_buffer_elems, libtripolar), Csize_t, (Cint, Cint, Cint, Cint, Cint, Cint),
+              nfields, size(grid, 1), Nz, halo_size(grid)[1], halo_size(grid)[2], Hz))
+
+# message buffers of one (architecture, nfields, element type, Nz, Hz) fill, kept across fills; one set per Julia task, so that
+# fills issued from different tasks (= different streams) never share staging memory
+const SEAM_BUFFERS = Dict{Any, NTuple{4, Any}}()
+function seam_buffers(arch, grid, nfields, FT, Nz, Hz)
+    get!(SEAM_BUFFERS, (arch, nfields, FT, Nz, Hz, size(grid), halo_size(grid), objectid(current_task()))) do
+        n = y_halo_buffer_elems(nfields, grid, Nz, Hz)
+        ntuple(_ -> device_array(arch, FT, n), 4)
+    end
+end
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 6. fill_halo_regions! on a tripolar grid                               src/zipper_boundary_condition.jl:140-155
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's `_fill_north_halo!(i, k, grid, c, bc::ZBC, loc, args...)` is a per-thread function inlined into
+# Oceananigans' south/north halo kernel; a ccall cannot live there.  The interception point is the method family where
+# Oceananigans hands over ALL sides of a field: `fill_halo_regions!(c::OffsetArray, bcs, indices, loc, grid, args...)`
+# (BoundaryConditions/fill_halo_regions.jl; for a DistributedGrid the method with the extra `buffers` argument,
+# DistributedComputations/halo_communication.jl) [recalled signatures, Oceananigans 0.95-0.99].  Specialising them on
+# `grid::TRG` / `grid::DTRG` takes the zipper, the periodic x pass AND the latitude-band seams away from KernelAbstractions
+# and MPI: they become tpg_fill_halo_regions / tpg_fill_halo_regions_distributed (hand-written HIP + RCCL).
+#
+# Order.  Oceananigans fills the three side pairs in the order given by `permute_boundary_conditions`: periodic and
+# communicating pairs LAST [recalled], i.e. on a tripolar field  south/north (the zipper)  ->  bottom/top  ->  west/east
+# (periodic; pinned against the zipper by test/test_zipper_boundary_conditions.jl:42-45)  [-> seams].  The bottom/top
+# conditions are Oceananigans' own (not part of the reference): when a field has none -- the 2-D free-surface and barotropic
+# fields, `bottom_height`, the reference's own coordinate / metric fills (src/tripolar_grid.jl:137-199,230-273) -- the whole
+# fill is ONE C call (one fused or merged launch); when it has some, the z pass must sit between the fold and the periodic
+# pass exactly as in the reference, so the fill is  tpg_zipper_fill -> Oceananigans' bottom/top launcher -> tpg_periodic_x_fill
+# (-> tpg_halo_exchange_y).
+loc_code(::Center) = Int8(0);  loc_code(::Type{Center}) = Int8(0)
+loc_code(::Face)   = Int8(1);  loc_code(::Type{Face})   = Int8(1)
+loc_code(::Nothing) = Int8(0); loc_code(::Type{Nothing}) = Int8(0)
+
+# (Nz, Hz) of ONE field from its own parent, z-location and indices -- never the grid's: a reduced field (LZ = Nothing, e.g.
+# bottom_height at (Center, Center, Nothing), test/test_zipper_boundary_conditions.jl:47-54) and a field windowed in z
+# (indices[3] a range: the parent holds exactly those levels, no z halo) have Hz = 0; a z-Face field has Nz + 1 levels.
+function field_levels(c, loc, indices, grid)
+    nlev = size(parent(c), 3)
+    LZ = loc[3]
+    (LZ === Nothing || LZ isa Nothing || !(indices[3] isa Colon)) && return nlev, 0
+    Hz = halo_size(grid)[3]
+    return nlev - 2Hz, Hz                              # Center: Nz, Face (Bounded z): Nz + 1
+end
+
+zipper_sign(bc::ZBC) = Int32(bc.condition)
+is_periodic(bc) = bc isa BoundaryCondition{<:Oceananigans.BoundaryConditions.Periodic}
+full_xy(indices) = indices[1] isa Colon && indices[2] isa Colon          # the kernels address the whole padded (x, y) parent
+
+"can the C ABI take this field's fill?  Periodic x, a Zipper (last rank / serial) or a seam on the north side, whole (x, y)"
+hip_fill_applies(bcs, indices, zipper_expected) =
+    full_xy(indices) && is_periodic(bcs.west) && is_periodic(bcs.east) && (!zipper_expected || bcs.north isa ZBC)
+
+# one C call per group of fields that share (element type, Nz, Hz): a tupled fill mixes 3-D and reduced fields
+function fill_groups(fields, locs, indices, grid)
+    groups = Dict{Tuple{DataType, Int, Int}, Vector{Int}}()
+    for (n, (c, loc)) in enumerate(zip(fields, locs))
+        Nz, Hz = field_levels(c, loc, indices, grid)
+        push!(get!(groups, (eltype(parent(c)), Nz, Hz), Int[]), n)
+    end
+    return groups
+end
+
+as_tuple(x::Tuple) = x
+as_tuple(x) = (x,)
+
+"""
+    hip_fill!(fields, bcs, locs, indices, grid; stage, comm = nothing, arch = nothing)
+
+The C-ABI part of one `fill_halo_regions!`, one batched call per geometry group.  `stage`:
+  :all       zipper -> periodic x (-> seams)   tpg_fill_halo_regions / tpg_fill_halo_regions_distributed  (no z conditions)
+  :zipper    the fold alone                     tpg_zipper_fill            (fold_north_*!, src/zipper_boundary_condition.jl:70-155)
+  :periodic  periodic x (-> seams)              tpg_periodic_x_fill (+ tpg_halo_exchange_y)
+"""
+function hip_fill!(fields, bcs, locs, indices, grid; stage::Symbol, comm = nothing, arch = nothing)
+    Nx, Ny, _ = size(grid)
+    Hx, Hy, _ = halo_size(grid)
+    zips = comm === nothing || comm.rank == comm.nranks - 1                     # the fold lives on the serial grid / the last rank
+    for ((FT, Nz, Hz), idx) in fill_groups(fields, locs, indices, grid)
+        fs   = [fields[n] for n in idx]
+        ptrs = Ptr{Cvoid}[device_pointer(f) for f in fs]
+        xloc = Int8[loc_code(locs[n][1]) for n in idx]
+        yloc = Int8[loc_code(locs[n][2]) for n in idx]
+        sgn  = Int32[zips ? zipper_sign(bcs[n].north) : Int32(1) for n in idx]
+        bufs = comm === nothing ? ntuple(_ -> nothing, 4) : seam_buffers(arch, grid, length(fs), FT, Nz, Hz)
+        bp   = map(b -> b === nothing ? C_NULL : device_pointer(b), bufs)
+        s    = current_stream()
+        GC.@preserve fs bufs begin
+            if stage === :zipper
+                zips && check(ccall((:tpg_zipper_fill, libtripolar), Cint,
+                            (Ptr{Ptr{Cvoid}}, Cint, Ptr{Int8}, Ptr{Int8}, Ptr{Int32}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
+                            ptrs, length(fs), xloc, yloc, sgn, Nx, Ny, Nz, Hx, Hy, Hz, 1, Nz, ft_code(FT), s))
+            elseif stage === :periodic
+                check(ccall((:tpg_periodic_x_fill, libtripolar), Cint,
+                            (Ptr{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
+                            ptrs, length(fs), Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), s))
+                comm === nothing || check(ccall((:tpg_halo_exchange_y, libtripolar), Cint,
+                            (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                             Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
+                            comm.handle, comm.rank, comm.nranks, ptrs, length(fs), bp[1], bp[2], bp[3], bp[4],
+                            Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), s))
+            elseif comm === nothing                                              # :all, serial grid: ONE launch (fused / merged)
+                check(ccall((:tpg_fill_halo_regions, libtripolar), Cint,
+                            (Ptr{Ptr{Cvoid}}, Cint, Ptr{Int8}, Ptr{Int8}, Ptr{Int32}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
+                            ptrs, length(fs), xloc, yloc, sgn, Nx, Ny, Nz, Hx, Hy, Hz, 1, ft_code(FT), s))
+            else                                                                 # :all, latitude band: zipper (last rank) -> periodic x -> RCCL seams
+                check(ccall((:tpg_fill_halo_regions_distributed, libtripolar), Cint,
+                            (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Int8}, Ptr{Int8}, Ptr{Int32},
+                             Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
+                            comm.handle, comm.rank, comm.nranks, ptrs, length(fs), xloc, yloc, sgn, bp[1], bp[2], bp[3], bp[4],
+                            Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), s))
+            end
+        end
+    end
+    return nothing
+end
+
+"`zipper_fill!(fields, bcs, locs, grid)`: the fold alone for fields given with their north conditions (kept for direct use)"
+zipper_fill!(fields, north_bcs, locs, grid; periodic_x::Bool = false) =
+    hip_fill!(as_tuple(fields), map(b -> (north = b,), as_tuple(north_bcs)), as_tuple(locs), (:, :, :), grid; stage = periodic_x ? :all : :zipper)
+
+# Oceananigans' own launchers for the sides this library does not fill (south; bottom / top) [recalled names and argument order:
+# fill_halo_event!(c, kernel!, bcs, indices, loc, arch, grid, args...) with the pair launchers fill_south_and_north_halo! /
+# fill_bottom_and_top_halo!; a `nothing` condition makes the corresponding side a no-op there]
+const OBC = Oceananigans.BoundaryConditions
+side(c, bs, f) = c isa Tuple ? map(f, bs) : f(bs[1])                          # tupled fill: tuples of conditions; single field: one
+south_only!(c, bs, indices, loc, arch, grid, args...; kwargs...) =
+    OBC.fill_halo_event!(c, OBC.fill_south_and_north_halo!, (side(c, bs, b -> b.south), side(c, bs, _ -> nothing)), indices, loc, arch, grid, args...; kwargs...)
+bottom_and_top!(c, bs, indices, loc, arch, grid, args...; kwargs...) =
+    OBC.fill_halo_event!(c, OBC.fill_bottom_and_top_halo!, (side(c, bs, b -> b.bottom), side(c, bs, b -> b.top)), indices, loc, arch, grid, args...; kwargs...)
+
+function tripolar_fill!(c, bcs, indices, loc, grid, comm, args...; kwargs...)
+    arch = architecture(grid)
+    cs, bs, ls = as_tuple(c), as_tuple(bcs), c isa Tuple ? loc : (loc,)
+    any(b -> !isnothing(b.south), bs) && south_only!(c, bs, indices, loc, arch, grid, args...; kwargs...)   # src/tripolar_grid.jl:148: `nothing` in the reference's own fills
+    if all(b -> isnothing(b.bottom) && isnothing(b.top), bs)
+        hip_fill!(cs, bs, ls, indices, grid; stage = :all, comm, arch)                      # one C call: fused / merged launch (+ seams)
+    else
+        hip_fill!(cs, bs, ls, indices, grid; stage = :zipper, comm, arch)
+        bottom_and_top!(c, bs, indices, loc, arch, grid, args...; kwargs...)
+        hip_fill!(cs, bs, ls, indices, grid; stage = :periodic, comm, arch)
+    end
+    return nothing
+end
+
+import Oceananigans.BoundaryConditions: fill_halo_regions!
+
+# serial tripolar grid: single field (c::OffsetArray, bcs::FieldBoundaryConditions) and the tupled fill (tuples of both)
+function fill_halo_regions!(c::Union{OffsetArray, NTuple{N, OffsetArray} where N}, bcs, indices, loc, grid::TRG, args...; kwargs...)
+    all(b -> hip_fill_applies(b, indices, true), as_tuple(bcs)) ||
+        return invoke(fill_halo_regions!, Tuple{Any, Any, Any, Any, Any, Vararg{Any}}, c, bcs, indices, loc, grid, args...; kwargs...)
+    return tripolar_fill!(c, bcs, indices, loc, grid, nothing, args...; kwargs...)
+end
+
+# latitude bands: the seams leave Oceananigans' MPI path (inject_halo_communication_boundary_conditions / FieldBoundaryBuffers,
+# src/distributed_tripolar_grid.jl:171,195) for ONE RCCL send/recv group per fill inside the C call; `buffers` (Oceananigans'
+# MPI staging buffers) stays unused
+function fill_halo_regions!(c::Union{OffsetArray, NTuple{N, OffsetArray} where N}, bcs, indices, loc, grid::DTRG, buffers, args...; kwargs...)
+    arch = architecture(grid)
+    last = arch.local_rank == ranks(arch.partition)[2] - 1
+    all(b -> hip_fill_applies(b, indices, last), as_tuple(bcs)) ||
+        return invoke(fill_halo_regions!, Tuple{Any, Any, Any, Any, Any, Any, Vararg{Any}}, c, bcs, indices, loc, grid, buffers, args...; kwargs...)
+    return tripolar_fill!(c, bcs, indices, loc, grid, seam_comm(arch), args...; kwargs...)
+end
+
 """
     halo_exchange_y!(comm, fields, locs, grid; buffers = nothing)
 
-The y-seam exchange of one `fill_halo_regions!` on a distributed tripolar grid: ONE RCCL send/recv group on the current
-stream, no host wait.  `buffers = (send_south, send_north, recv_south, recv_north)` device arrays of
-`tpg_y_halo_buffer_elems` elements select the packed form; `nothing` the pack-free form (per-level seam windows sent
-from / received into the fields).  Call after the zipper (last rank) and the periodic-x pass of the same fill.
+The y-seam exchange alone (what the DTRG method above issues after the periodic pass), for direct use: ONE RCCL send/recv
+group on the current stream, no host wait.  `buffers = (send_south, send_north, recv_south, recv_north)` device arrays of
+`y_halo_buffer_elems` elements select the packed form; `nothing` the pack-free form (one RCCL operation per (field, level):
+2-D and few-level fields only).
 """
 function halo_exchange_y!(comm::SeamComm, fields, locs, grid; buffers = nothing)
     Nx, Ny, _ = size(grid)
     Hx, Hy, _ = halo_size(grid)
-    for ((FT, Nz, Hz), idx) in zipper_groups(fields, locs, grid)
+    for ((FT, Nz, Hz), idx) in fill_groups(fields, locs, (:, :, :), grid)
         fs   = [fields[n] for n in idx]
         ptrs = Ptr{Cvoid}[device_pointer(f) for f in fs]
         bp   = isnothing(buffers) ? ntuple(_ -> C_NULL, 4) : map(b -> isnothing(b) ? C_NULL : device_pointer(b), buffers)
@@ -406,10 +501,6 @@ function halo_exchange_y!(comm::SeamComm, fields, locs, grid; buffers = nothing)
     end
     return nothing
 end
-
-y_halo_buffer_elems(nfields, grid, Nz, Hz) =
-    Int(ccall((:tpg_y_halo_buffer_elems, libtripolar), Csize_t, (Cint, Cint, Cint, Cint, Cint, Cint),
-              nfields, size(grid, 1), Nz, halo_size(grid)[1], halo_size(grid)[2], Hz))
 
 # ---------------------------------------------------------------------------------------------------------------------
 # 7. Geometry utilities                 test/test_tripolar_grid.jl:8-34,70; examples/convert_to_latlong_frame.jl:12-55
