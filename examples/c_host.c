@@ -75,6 +75,21 @@ int main(void)
 #define U(i, j) h[(size_t)((i) + H - 1) + fsx * ((size_t)((j) + H - 1) + fsy * (size_t)H)]
         printf("zipper 10x10x1, u = 1, sign -1: u[2, Ny+1] = %g, u[1, Ny+1] = %g, u[Nx+1, Ny+1] = %g, u[Nx/2+1, Ny+4] = %g\n",
                U(2, Ny + 1), U(1, Ny + 1), U(Nx + 1, Ny + 1), U(Nx / 2 + 1, Ny + 4));
+        /* the same fill through the distributed entry point on a chain of ONE latitude band (no seam, no communicator):
+           zipper -> periodic x -> (no exchange).  The folded pole point of row Ny flips sign on every fill (a quirk of the
+           reference, src/zipper_boundary_condition.jl:90,102), everything else is idempotent */
+        TPGCHECK(tpg_fill_halo_regions_distributed(NULL, 0, 1, fields, 1, xloc, yloc, sign, NULL, NULL, NULL, NULL,
+                                                   Nx, Ny, Nz, H, H, H, TPG_F64, NULL));
+        HIPCHECK(hipDeviceSynchronize());
+        {
+            double *h2 = (double *)malloc(n3 * sizeof(double));
+            size_t q2, diff = 0;
+            HIPCHECK(hipMemcpy(h2, u, n3 * sizeof(double), hipMemcpyDeviceToHost));
+            for (q2 = 0; q2 < n3; ++q2) diff += (h2[q2] != h[q2]);
+            printf("distributed entry point, one band: %lu cells differ from the serial fill (the pole point u[Nx/2+1, Ny]); rccl %s\n",
+                   (unsigned long)diff, tpg_comm_available() == TPG_OK ? "bound" : "absent");
+            free(h2);
+        }
         /* an argument error comes back as a status + message, never as an exception across the boundary */
         printf("odd Nlambda -> status %d: %s\n",
                tpg_fill_halo_regions(fields, 1, xloc, yloc, sign, 11, Ny, Nz, H, H, H, 1, TPG_F64, NULL), tpg_last_error());

@@ -43,3 +43,6 @@ def test_c_host_reproduces_the_reference_known_answers(gpu, kats, tmp_path):
     assert inner == z["u_north_halo_i_2_to_Nx_minus_1"] and left == z["u_north_halo_i_1"] and right == z["u_north_halo_i_Nx_plus_1"]
     assert mid == -1.0
     assert "status -2" in out and "even" in out
+    # the distributed entry point on a one-band chain is the serial fill: only the self-mapped pole point (sign -1) changes again
+    m = re.search(r"one band: (\d+) cells differ", out)
+    assert m and int(m.group(1)) == 1, out

@@ -343,6 +343,48 @@ __global__ __launch_bounds__(256) void k_per4(Fields ft, long long nrows)
     else if (b + 1 < nrows) { double* c = base + (b + 1) * SX; c[q - 4] = c[NX + (q - 4)]; }
 }
 
+// P5: cache-policy variants of the periodic pass (round 3).  The pass is bound by line transfers, not bytes: per row pair 3
+// whole 128-B lines are fetched (for 128 B of sources) and 3 lines are dirtied.  Do scoped / non-temporal accesses change
+// what crosses the L2 <-> memory boundary (sector-sized fetches, write-through instead of write-back)?
+//   shape: the 8-byte-lane row-boundary form of P4 (scoped atomics exist for 8-byte accesses), or the 16-byte product form (LD/ST <= 1)
+//   LD: 0 plain, 1 nontemporal, 2 agent-scope relaxed atomic load (sc1), 3 system-scope (sc0 sc1)
+//   ST: 0 plain, 1 nontemporal, 2 agent-scope relaxed atomic store,      3 system-scope
+template <int LD> __device__ __forceinline__ double ld8(const double* p)
+{
+    if (LD == 1) return __builtin_nontemporal_load(p);
+    if (LD == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (LD == 3) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return *p;
+}
+template <int ST> __device__ __forceinline__ void st8(double* p, double v)
+{
+    if (ST == 1) __builtin_nontemporal_store(v, p);
+    else if (ST == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (ST == 3) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *p = v;
+}
+template <int LD, int ST>
+__global__ __launch_bounds__(256) void k_per5(Fields ft, long long nrows)
+{
+    long long it = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (it >= (nrows + 1) * 8) return;
+    long long b = (it >> 3) - 1; int q = (int)(it & 7);
+    double* base = ft.p[blockIdx.y];
+    if (q < 4) { if (b >= 0) { double* c = base + b * SX; st8<ST>(c + H + NX + q, ld8<LD>(c + H + q)); } }
+    else if (b + 1 < nrows) { double* c = base + (b + 1) * SX; st8<ST>(c + (q - 4), ld8<LD>(c + NX + (q - 4))); }
+}
+// P6: the 16-byte product form with non-temporal loads (and optionally non-temporal stores)
+template <int ST>
+__global__ __launch_bounds__(256) void k_per6(Fields ft, long long nrows)
+{
+    long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= nrows * 2) return;
+    long long row = item >> 1; int v = (int)(item & 1);
+    u4* c = reinterpret_cast<u4*>(ft.p[blockIdx.y] + row * SX);
+    u4 w = __builtin_nontemporal_load(c + NX / 2 + v), e = __builtin_nontemporal_load(c + H / 2 + v);
+    if (ST) { __builtin_nontemporal_store(w, c + v); __builtin_nontemporal_store(e, c + H / 2 + NX / 2 + v); }
+    else { c[v] = w; c[H / 2 + NX / 2 + v] = e; }
+}
 
 // Two half-row-apart chunks per thread: 4224 waves = one resident round on 8192 wave slots (the one-chunk
 // form launches 8448), 8-10 independent 16-B loads per thread.
@@ -619,6 +661,30 @@ int main(int argc, char** argv)
         { dim3 grid((unsigned)(((nrows + 1) * 8 + 255) / 256), NF);
           auto r = run3([&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(k_per4, grid, dim3(256), 0, 0, a, b, 0, g_ft, nrows); }, rounds);
           report("per4 boundary 8-B lanes", r, pbytes); }
+    }
+    if (exp == "perx") {
+        // interleaved A/B of the cache-policy variants; device durations come from the rocprofv3 kernel trace of this run
+        // (run.sh), the fetch / write bytes from its --pmc passes (run.sh perx pmc)
+        dim3 g8((unsigned)(((nrows + 1) * 8 + 255) / 256), NF);
+        dim3 g16((unsigned)((nrows * 2 + 255) / 256), NF);
+        for (int it = 0; it < rounds + 2; ++it)
+            for (int v = 0; v < 11; ++v) {
+                hipLaunchKernelGGL(k_flush_clean, dim3(8192), dim3(256), 0, 0, g_flush, FLUSH_N, g_flush);
+                switch (v) {
+                case 0: hipLaunchKernelGGL(k_per0, g16, dim3(256), 0, 0, g_ft, nrows); break;
+                case 1: hipLaunchKernelGGL(k_per6<0>, g16, dim3(256), 0, 0, g_ft, nrows); break;
+                case 2: hipLaunchKernelGGL(k_per6<1>, g16, dim3(256), 0, 0, g_ft, nrows); break;
+                case 3: hipLaunchKernelGGL((k_per5<0, 0>), g8, dim3(256), 0, 0, g_ft, nrows); break;
+                case 4: hipLaunchKernelGGL((k_per5<1, 0>), g8, dim3(256), 0, 0, g_ft, nrows); break;
+                case 5: hipLaunchKernelGGL((k_per5<2, 0>), g8, dim3(256), 0, 0, g_ft, nrows); break;
+                case 6: hipLaunchKernelGGL((k_per5<3, 0>), g8, dim3(256), 0, 0, g_ft, nrows); break;
+                case 7: hipLaunchKernelGGL((k_per5<0, 2>), g8, dim3(256), 0, 0, g_ft, nrows); break;
+                case 8: hipLaunchKernelGGL((k_per5<0, 3>), g8, dim3(256), 0, 0, g_ft, nrows); break;
+                case 9: hipLaunchKernelGGL((k_per5<3, 3>), g8, dim3(256), 0, 0, g_ft, nrows); break;
+                case 10: hipLaunchKernelGGL((k_per5<1, 1>), g8, dim3(256), 0, 0, g_ft, nrows); break;
+                }
+            }
+        CHECK(hipDeviceSynchronize());
     }
     CHECK(hipDeviceSynchronize());
     printf("done\n");

@@ -12,6 +12,26 @@ cd /tmp && export TMPDIR=/tmp
 if [ "$EXP" = timeline ]; then
   "$BIN" timeline > "$OUT/log.txt" 2>&1; echo "rc=$?"; cat "$OUT/log.txt"; exit 0
 fi
+if [ "$3" = pmc ]; then    # separate counter passes (kernel-trace only beside --pmc): bytes fetched / written per launch, by kernel
+  for CNT in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d "$OUT/$CNT" -o fb -- "$BIN" "$EXP" 3 > "$OUT/log_$CNT.txt" 2>&1; echo "pmc $CNT rc=$?"
+  done
+  python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+acc = collections.OrderedDict()
+for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(sys.argv[1] + "/" + cnt + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == cnt and "k_per" in r["Kernel_Name"]:
+                acc.setdefault(r["Kernel_Name"][:60], {}).setdefault(cnt, []).append(float(r["Counter_Value"]))
+print("PMC per launch (KiB counters -> MB; FETCH_SIZE doubled for gfx950's 128-B requests, MI355X_MICROARCH.md):")
+for k, d in acc.items():
+    fe = 2 * 1024 * sum(d.get("FETCH_SIZE", [0])) / max(1, len(d.get("FETCH_SIZE", [0]))) / 1e6
+    wr = 1024 * sum(d.get("WRITE_SIZE", [0])) / max(1, len(d.get("WRITE_SIZE", [0]))) / 1e6
+    print(f"  {k:60s} fetch {fe:8.1f} MB  write {wr:8.1f} MB")
+PY
+  exit 0
+fi
 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o fb -- "$BIN" "$EXP" "$ROUNDS" > "$OUT/log.txt" 2>&1
 echo "rocprofv3 rc=$?"
 cat "$OUT/log.txt"
