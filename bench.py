@@ -196,11 +196,11 @@ def main():
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
     strong = world > 1 and args.scaling == "strong"
     if strong and NY % world:
         # the remainder rule of Oceananigans' local_size for Ny % R != 0 is unpinned: config 4 divides evenly
         raise SystemExit(f"--scaling strong needs {NY} % N == 0 (N = {world}); use N in 1,2,3,4,5,6,8,... or --scaling weak")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
     rehearse = os.environ.get("TPG_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0

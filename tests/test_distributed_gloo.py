@@ -95,3 +95,42 @@ def test_latitude_band_halo_exchange_over_gloo(world):
         msgs.append(errors.get())
     assert not msgs, msgs
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def _readiness_worker(rank, world, port, results):
+    """RcclComm.from_torch with librccl 'unavailable' on rank 1: every rank must leave with the same RuntimeError BEFORE anyone
+    enters the collective ncclCommInitRank (round 2: the ranks that could bind librccl blocked inside it)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import orthogonalsphericalshellgrids.jl_amd as osg
+    osg.RcclComm.available = staticmethod(lambda: rank != 1)
+    entered = []
+    osg.RcclComm.create = classmethod(lambda cls, *a: entered.append(a) or (_ for _ in ()).throw(AssertionError("ncclCommInitRank entered")))
+    try:
+        osg.RcclComm.from_torch()
+        results.put((rank, "no error"))
+    except RuntimeError as e:
+        results.put((rank, str(e)))
+    assert not entered
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_readiness_is_agreed_before_the_collective_init():
+    world = 3
+    ctx = mp.get_context("spawn")
+    results = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_readiness_worker, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = {}
+    while not results.empty():
+        r, msg = results.get()
+        got[r] = msg
+    assert set(got) == {0, 1, 2} and all("librccl unavailable on rank(s) [1]" in m for m in got.values()), got

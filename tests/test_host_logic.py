@@ -119,3 +119,41 @@ def test_loopback_mailbox_delivers_in_order(osg):
 def test_rccl_comm_rejects_a_malformed_unique_id(osg):
     with pytest.raises(ValueError):
         osg.RcclComm.create(b"short", 0, 1)
+
+
+def test_bench_watchdog_fires_with_one_json_line():
+    """bench.py's deadline for the first contact with other ranks: on expiry ONE JSON line (rank, peers, phase) on stderr and
+    os._exit(3) -- also when the main thread is blocked in a host call (here: a sleep)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "d = bench.Watchdog(0.3, {'rank': 2, 'world': 8, 'peers': {'south': 1, 'north': 3}})\n"
+            "d.arm('first seam exchange: enqueue'); d.set_phase('first seam exchange: device')\n"
+            "time.sleep(20); print('not reached')\n" % root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3 and "not reached" not in p.stdout
+    lines = [l for l in p.stderr.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["event"] == "bench_deadline_expired" and d["rank"] == 2 and d["peers"] == {"south": 1, "north": 3}
+    assert d["phase"] == "first seam exchange: device" and d["deadline_s"] == 0.3
+    # a disarmed watchdog does nothing
+    code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+             "d = bench.Watchdog(0.2, {}); d.arm('x'); d.disarm(); time.sleep(0.6); print('alive')\n" % root)
+    p2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60)
+    assert p2.returncode == 0 and "alive" in p2.stdout
+
+
+def test_bench_refuses_a_strong_split_that_does_not_divide():
+    """config 4 divides the 1800 rows evenly; the remainder rule for Ny % R != 0 is Oceananigans-internal (unpinned), so the
+    strong-scaling bench refuses such an N before touching a device"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="7", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "7"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0 and "1800 % N == 0" in p.stderr and not p.stdout.strip()
