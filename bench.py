@@ -374,14 +374,17 @@ def main():
         dog.disarm()
 
     # ---- auxiliary measurements (not steps) ----------------------------------------------------------------------------------
+    # Order: the config-5 block first (it allocates and frees 162 GB), the config-3 auxiliary block last.  Neither order changes
+    # what the first timed steps see: the FP64-heavy cell kernel starts a power-management transient whenever it follows lighter
+    # work -- 535 us on its first launch, up to 690 us a few launches later, back to its steady 490 us only after ~40 launches
+    # (~25 ms; profiles/r03/cells_sequence_driver_args.txt).  `--steps 20 --warmup 5` times exactly that transient (0.64-0.66 ms per
+    # step); the defaults (50 + 200 steps) time the steady state (0.56-0.58 ms).  DESIGN.md 6 quotes both.
+    fill_step = None
+    if world == 1 and not args.no_fill_step:
+        fill_step = fill_step_config5(torch, osg, _lib, tlib, dev)
     aux = {}
     if world == 1 and not args.no_aux:
         aux = auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, sg, geom, p, out, out_ptrs, ws, hip_event, elapsed_ms)
-    fill_step = None
-    if world == 1 and not args.no_fill_step:
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()                                    # hand the auxiliary buffers back before sizing 162 GB of fields
-        fill_step = fill_step_config5(torch, osg, _lib, tlib, dev)
 
     # ---- W warm-up steps, K timed steps ------------------------------------------------------------------------------------
     sync()
