@@ -7,14 +7,17 @@ side; reached from :171,195).  Here: one process per GPU; each interior seam swa
 send/recv over xGMI.  No collective is involved: a y-slab chain only ever talks to its two neighbours.
 
 Three transports, all bit-identical in what they deliver:
-  * RcclComm (the production path): the C ABI's tpg_halo_exchange_y -- pack -> ONE ncclGroupStart/End of
-    ncclSend/ncclRecv on the caller's stream -> unpack (or pack-free: the per-level contiguous seam windows sent
-    from / received into the fields directly).  No host wait.  The communicator is
-    librccl's own (tpg_comm_init_rank); torch.distributed only ferries the 128-byte unique id.
+  * RcclComm (the production path): the C ABI's tpg_fill_halo_regions_distributed -- the WHOLE fill of a band in one call: zipper
+    (last rank) -> periodic x -> tpg_halo_exchange_y = pack -> ONE ncclGroupStart/End of ncclSend/ncclRecv on the caller's stream ->
+    unpack (or pack-free: the per-level contiguous seam windows sent from / received into the fields directly).  No host wait.
+    HaloFillPlan issues that call when the architecture carries an RcclComm.  The communicator is librccl's own
+    (tpg_comm_init_rank); torch.distributed only ferries the 128-byte unique id, after every rank has reported that it can bind librccl.
   * torch_distributed_transport: `batch_isend_irecv` of the packed messages (backend "nccl" = RCCL, or "gloo" with
     host tensors): the Python convenience, and what the CPU/gloo tests of the host protocol run.
   * any object with post(plan, send, recv, group) / wait(handle) (two-phase), or a plain callable
     transport(plan, send, recv, group): test transports (loop-back emulation of R ranks on one GPU, host staging).
+Message buffers belong to the exchange object (one SeamBuffers per batch of TPG_MAX_FIELDS fields), never to a module-level cache:
+two plans or two batches that are in flight together must not share staging memory.
 """
 import ctypes as C
 from dataclasses import dataclass
