@@ -36,7 +36,7 @@ class Field:
     (distributed_tripolar_grid.jl:171,177-185).
     """
 
-    def __init__(self, loc, grid, data=None, boundary_conditions="default", name=None):
+    def __init__(self, loc, grid, data=None, boundary_conditions="default", name=None, indices=(slice(None), slice(None), slice(None))):
         if not is_tripolar(grid):
             raise TypeError("Field: grid must be a TripolarGrid")
         LX, LY, LZ = loc
@@ -51,6 +51,24 @@ class Field:
         else:
             self.Nz = g.Nz + (1 if LZ is Face else 0)   # Bounded z: Nz+1 faces
             self.Hz = g.Hz
+        # validate_indices (src/tripolar_grid_extensions.jl:58): `indices` = (:, :, k1:k2) windows the field in z -- given here as a
+        # range of 1-based levels, range(k1, k2 + 1), or one level k.  The parent of a windowed dimension holds exactly those levels
+        # and no halo [recalled: Oceananigans offset_data], so the kernels see Nz = k2 - k1 + 1, Hz = 0.  Windows in x or y are
+        # Oceananigans' own fill: the kernels address whole padded rows.
+        full = slice(None)
+        ix, iy, iz = indices
+        if ix != full or iy != full:
+            raise NotImplementedError("Field: indices windowed in x or y are not handled by this library (whole padded rows only)")
+        self.z_window = None
+        if iz != full:
+            if LZ is None:
+                raise ValueError("Field: a field reduced in z cannot be windowed in z")
+            levels = range(iz, iz + 1) if isinstance(iz, int) else iz
+            if not isinstance(levels, range) or levels.step != 1 or len(levels) < 1 or levels[0] < 1 or levels[-1] > self.Nz:
+                raise ValueError(f"Field: z indices {iz!r} outside 1:{self.Nz} (a range of consecutive 1-based levels, or one level)")
+            self.z_window = (levels[0], levels[-1])
+            self.Nz, self.Hz = len(levels), 0
+        self.indices = (full, full, iz)
         shape = (self.Nz + 2 * self.Hz, self.Ny + 2 * self.Hy, self.Nx + 2 * self.Hx)
         if data is None:
             data = torch.zeros(shape, dtype=g.dtype, device=g.device)
@@ -103,7 +121,8 @@ class Field:
                 z = torch.zeros(1, dtype=g.dtype, device=g.device)
             else:
                 zz = g.z_faces if self.loc[2] is Face else g.z_centers
-                z = zz[self.Hz:self.Hz + self.Nz]
+                k0 = g.Hz + (self.z_window[0] - 1 if self.z_window else 0)
+                z = zz[k0:k0 + self.Nz]
             value = value(lam[None, :, :].to(inter.dtype), phi[None, :, :].to(inter.dtype), z[:, None, None])
         inter.copy_(torch.as_tensor(value, dtype=inter.dtype, device=inter.device).expand_as(inter))
         return self

@@ -346,3 +346,35 @@ def test_halo_fill_plan_graph_replay(osg, oracle, gpu):
         for _ in range(2):
             oracle.fill_halo_regions(h, xl, yl, sg, (size[0], size[1], 1), (halo[0], halo[1], 0))
         assert np.array_equal(f.data.cpu().numpy(), h), f.loc
+
+
+def test_z_windowed_fields(osg, oracle, gpu):
+    """Field(loc, grid; indices = (:, :, k1:k2)) (validate_indices, src/tripolar_grid_extensions.jl:58): the parent of a field windowed
+    in z holds exactly those levels and no z halo, so the fill runs with Nz = k2 - k1 + 1, Hz = 0 -- e.g. the surface slice of u.
+    Windows in x or y and levels outside the grid are refused."""
+    size, halo = (64, 24, 6), (4, 4, 3)
+    grid = osg.TripolarGrid(osg.GPU(0), torch.float64, size=size, halo=halo)
+    full = slice(None)
+    u_top = osg.Field((osg.Face, osg.Center, osg.Center), grid, indices=(full, full, 6))                 # k = Nz: one level
+    c_win = osg.Field((osg.Center, osg.Center, osg.Center), grid, indices=(full, full, range(2, 5)))      # k = 2:4
+    w_top = osg.Field((osg.Center, osg.Center, osg.Face), grid, indices=(full, full, 7))                  # z-Face: Nz + 1 levels exist
+    assert (u_top.Nz, u_top.Hz, tuple(u_top.data.shape)) == (1, 0, (1, 32, 72))
+    assert (c_win.Nz, c_win.Hz, tuple(c_win.data.shape)) == (3, 0, (3, 32, 72)) and w_top.Nz == 1
+    rng = np.random.default_rng(8)
+    hosts = []
+    for f in (u_top, c_win, w_top):
+        h = rng.uniform(-1, 1, tuple(f.data.shape))
+        f.data.copy_(torch.from_numpy(h)); hosts.append(h)
+    osg.fill_halo_regions([u_top, c_win, w_top])
+    torch.cuda.synchronize()
+    for f, h, (xl, yl, sg) in zip((u_top, c_win, w_top), hosts, ((1, 0, -1), (0, 0, 1), (0, 0, 1))):
+        oracle.fill_halo_regions(h, xl, yl, sg, (64, 24, f.Nz), (4, 4, 0))
+        assert np.array_equal(f.data.cpu().numpy(), h), f.loc
+    c_win.set_(lambda x, y, z: z)                                      # z nodes of the window: levels 2..4 of the grid's centres
+    assert torch.equal(c_win.interior()[:, 0, 0], grid.z_centers[3 + 1:3 + 4].to(torch.float64))
+    with pytest.raises(NotImplementedError):
+        osg.Field((osg.Center, osg.Center, osg.Center), grid, indices=(range(1, 9), full, full))
+    with pytest.raises(ValueError):
+        osg.Field((osg.Center, osg.Center, osg.Center), grid, indices=(full, full, range(5, 8)))
+    with pytest.raises(ValueError):
+        osg.Field((osg.Center, osg.Center, None), grid, indices=(full, full, 1))
