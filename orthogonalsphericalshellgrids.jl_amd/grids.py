@@ -90,6 +90,13 @@ class Distributed:
         return f"Distributed({self.child_architecture!r}, ranks={self.ranks}, local_rank={self.local_rank})"
 
 
+def convert_to_0_360(x):
+    """convert_to_0_360(x) = ((x % 360) + 360) % 360  (src/OrthogonalSphericalShellGrids.jl:24); Julia's `%` is the truncated
+    remainder (C fmod), not Python's floored one"""
+    import math
+    return math.fmod(math.fmod(x, 360) + 360, 360)
+
+
 def child_architecture(arch):
     return arch.child_architecture if getattr(arch, "is_distributed", False) else arch
 

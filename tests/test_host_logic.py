@@ -157,3 +157,9 @@ def test_bench_refuses_a_strong_split_that_does_not_divide():
     env = dict(os.environ, WORLD_SIZE="7", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "7"], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode != 0 and "1800 % N == 0" in p.stderr and not p.stdout.strip()
+
+
+def test_convert_to_0_360(osg):
+    """src/OrthogonalSphericalShellGrids.jl:24 with Julia's truncated `%`"""
+    f = osg.convert_to_0_360
+    assert f(0.0) == 0.0 and f(360.0) == 0.0 and f(-90.0) == 270.0 and f(725.5) == 5.5 and f(-725.5) == 354.5 and f(359.9999) == 359.9999
