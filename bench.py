@@ -443,6 +443,12 @@ def main():
             t_fill_kernel = sum(elapsed_ms(e0, e1) for e0, e1 in kev2) / len(kev2)
             for e0, e1 in kev2:
                 lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
+        # every rank's own phase times (instrumented pass) travel to rank 0 for the line: at N = 8 the interior ranks carry two
+        # seams, the end ranks one, and only the north rank folds
+        mine = {"rank": rank, "rows": [jstart, jend], "build_ms": t_build, "local_fill_ms": t_fill_bracket, "exchange_ms": t_exchange,
+                "fill_plus_exchange_ms": t_fillx, "seams": int(rank > 0) + int(not north_rank), "zipper": north_rank}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         t_build_max, t_exchange, t_fillx = reduce_max(t_build), reduce_max(t_exchange), reduce_max(t_fillx)
         t_fill_kernel = reduce_max(t_fill_kernel)                                    # only the north rank has one
         t_build = t_build_max
@@ -497,6 +503,7 @@ def main():
                 "exchange_transport": ("gloo, host-staged (rehearsal: timings meaningless)" if rehearse
                                        else ("tpg_fill_halo_regions_distributed -> tpg_halo_exchange_y: librccl ncclSend/ncclRecv group, packed messages"
                                              if comm is not None else "torch.distributed batch_isend_irecv (nccl = RCCL), packed messages [fallback]")),
+                "per_rank": per_rank,
                 "seam_message_bytes_per_direction": seam_bytes,
                 "seam_GBps_per_direction": seam_bytes / (t_exchange * 1e-3) / 1e9,
                 "note": "no multi-GPU curve exists until the driver runs one: this line is what each N prints"})

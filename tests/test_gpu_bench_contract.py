@@ -88,6 +88,9 @@ def test_bench_two_ranks_rehearsal(gpu):
     assert d["exchange_over_build"] > 0 and d["fill_plus_exchange_ms"] >= d["exchange_ms"]
     assert abs(d["value"] - 3600 * 1800 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]            # the globe is fixed: strong
     assert d["precompute_cells_per_s"] > 0 and d["roofline"]["launch_ms"] > 0
+    pr = d["per_rank"]                                                # every rank's own phase times
+    assert [r["rank"] for r in pr] == [0, 1] and pr[0]["rows"] == [1, 900] and pr[1]["rows"] == [901, 1800]
+    assert [r["zipper"] for r in pr] == [False, True] and [r["seams"] for r in pr] == [1, 1] and all(r["build_ms"] > 0 for r in pr)
     assert "cpu_baseline" not in d and "fill_step" not in d           # rank 0 at N = 1 only
     w = _two_rank_bench(["--scaling", "weak"])
     assert w["scaling"] == "weak" and w["config"]["global_size"] == [3600, 3600, 75] and w["config"]["local_size"] == [3600, 1800, 75]
