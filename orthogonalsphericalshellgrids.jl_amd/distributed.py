@@ -81,7 +81,7 @@ torch_distributed_transport = TorchDistributedTransport()
 
 class LoopbackMailbox:
     """Two-phase transport for R latitude-band ranks emulated in ONE process on one GPU (tests/test_gpu_distributed.py,
-    tools/soak_distributed.py): post() parks the rank's packed messages in a shared mailbox, wait() delivers the peers'
+    tests/soak/soak_distributed.py): post() parks the rank's packed messages in a shared mailbox, wait() delivers the peers'
     messages into the receive buffers.  Drive it as: plan_r.begin() for every rank r, then plan_r.finish() for every r."""
 
     def __init__(self):

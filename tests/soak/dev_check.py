@@ -1,6 +1,6 @@
 """Developer diagnostic (GPU box): parity of build_grid / zipper against the oracle + rough timings."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import orthogonalsphericalshellgrids.jl_amd as osg
 from oracle import oracle

@@ -2,7 +2,7 @@
 transport (real kernels: zipper on the north rank, periodic x, pack / unpack).  Every rank's slab must equal
 rows jstart-Hy..jend+Hy of the serially filled global field (oracle).  usage: soak_distributed.py [trials] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import orthogonalsphericalshellgrids.jl_amd as osg
 from oracle import oracle

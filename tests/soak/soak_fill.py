@@ -1,8 +1,8 @@
 """GPU box: randomised soak of the halo fill (tpg_fill_halo_regions: zipper -> periodic x) against the oracle,
 bit-exact on whole padded arrays: random geometry, locations, signs, element types, zipper variants, fused and
-two-launch forms.  usage: python tools/soak_fill.py [trials] [seed]"""
+two-launch forms.  usage: python tests/soak/soak_fill.py [trials] [seed]"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import orthogonalsphericalshellgrids.jl_amd as osg
 from orthogonalsphericalshellgrids.jl_amd import _lib

@@ -1,8 +1,8 @@
 """GPU box: extended randomised soak of tpg_build_grid against the oracle (bit-exact, whole padded arrays):
 sizes up to 400 x 120, continuous random poles / south / first-pole longitude / radius, both element types,
-both the tile and the marching kernels.  usage: python tools/soak_grid.py [trials] [seed] [big]"""
+both the tile and the marching kernels.  usage: python tests/soak/soak_grid.py [trials] [seed] [big]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import orthogonalsphericalshellgrids.jl_amd as osg
 from oracle import oracle

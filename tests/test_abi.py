@@ -150,3 +150,25 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                         "-o", str(tmp_path / "abi.o")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_only_the_checker_sites_load_the_oracle():
+    """oracle/ is test infrastructure: besides tests/ (incl. tests/soak/), only __graft_entry__.smoke() and bench.py's cpu_baseline()
+    may import it -- tools/ and examples/ may not, and bench.py may not outside that one function"""
+    import ast
+    for sub in ("tools", "examples"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".c", ".hip")):
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert not re.search(r"^\s*(from oracle|import oracle)", text, flags=re.M), os.path.join(dirpath, f)
+    for name, allowed in (("bench.py", {"cpu_baseline"}), ("__graft_entry__.py", {"smoke"})):
+        tree = ast.parse(open(os.path.join(ROOT, name)).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.FunctionDef):
+                imports = [n for n in ast.walk(node) if isinstance(n, (ast.Import, ast.ImportFrom))
+                           and ("oracle" in (getattr(n, "module", None) or "") or any("oracle" in a.name for a in n.names))]
+                assert not imports or node.name in allowed, (name, node.name)
+        top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))
+               and ("oracle" in (getattr(n, "module", None) or "") or any("oracle" in a.name for a in n.names))]
+        assert not top, name

@@ -147,7 +147,7 @@ def test_latitude_bands_equal_slices_of_the_global_grid(osg, oracle, gpu, R):
 def test_bands_thinner_than_the_halo(osg, oracle, gpu, size, halo, R):
     """A band whose halo reaches past its neighbour sees row Ny (with its substitution) and north fold rows even
     though it is not the north rank: the reference slices these out of the global padded arrays
-    (distributed_tripolar_grid.jl:47-49,112-120); found by tools/soak_grid.py."""
+    (distributed_tripolar_grid.jl:47-49,112-120); found by tests/soak/soak_grid.py."""
     glob = oracle.build_grid(size, halo=halo)
     for r in range(R):
         arch = osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=r)
