@@ -51,12 +51,32 @@ template <int N> TPG_DEV void kcos_b(const double (&x)[N], const double (&y)[N],
 // sin(x) for |x| <= pi/4 (the haversine's half-differences).  tpgm::sinD returns x for
 // |x| < 2^-26: ksin(x, 0) = x - x^3/6 (1 - ...) rounds to x there (|x^2/6| < 2^-54), also for +-0.
 // rare: some |x| > pi/4 (seam-crossing longitude differences) -> caller uses tpgm::sinD.
+// ksin(x, 0): the y = 0 form of ksin_b with the two operations on y removed.  ksin_b evaluates x - ((z (0.5 y - v r) - y) - v S1);
+// with y = +0 the inner difference is 0 - v r and "- y" is the identity.  0 - t equals -t except for t = +0 (0 - 0 = +0, -(+0) = -0),
+// and that sign never reaches the result: t = v r = +0 only when v = +0 (r > 0), z (-+0) is a zero of either sign, the next term
+// v S1 is then -0 (S1 < 0) and (+-0) - (-0) = +0 in both cases.  So z * -(v r) gives the bits of z * (0 - v r) - 0 everywhere
+// (checked argument by argument against the scalar sinD, signed zeros and subnormals included: tests/test_gpu_math.py) -- one VALU
+// instruction less per sine, 16 per cell of the metric kernel.
+template <int N> TPG_DEV void ksin0_b(const double (&x)[N], double (&out)[N])
+{
+    double z[N], r[N], v[N];
+    TPG_UNROLL for (int e = 0; e < N; ++e) z[e] = x[e] * x[e];
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], r[e], 2.75573137070700676789e-06);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], r[e], -1.98412698298579493134e-04);
+    TPG_UNROLL for (int e = 0; e < N; ++e) r[e] = fmaD(z[e], r[e], 8.33333333332248946124e-03);
+    TPG_UNROLL for (int e = 0; e < N; ++e) v[e] = z[e] * x[e];
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        const double t = v[e] * r[e];
+        out[e] = x[e] - (z[e] * -t - v[e] * -1.66666666666666324348e-01);
+    }
+}
+
 template <int N> TPG_DEV bool sin_small_b(const double (&x)[N], double (&out)[N])
 {
-    double y[N];
     bool rare = false;
-    TPG_UNROLL for (int e = 0; e < N; ++e) { y[e] = 0.0; rare |= !(absD(x[e]) <= kPio4Hi); }
-    ksin_b<N>(x, y, out);
+    TPG_UNROLL for (int e = 0; e < N; ++e) rare |= !(absD(x[e]) <= kPio4Hi);
+    ksin0_b<N>(x, out);
     return rare;
 }
 
@@ -74,7 +94,10 @@ template <int N> TPG_DEV bool cos_b(const double (&a)[N], double (&out)[N])
         double w = fn[e] * kPio2_1t;
         y0[e] = r - w;
         y1[e] = (r - y0[e]) - w;
-        rare |= (expo(a[e]) - expo(y0[e]) > 16);
+        // the scalar code iterates when the exponents of a and y0 differ by more than 16, i.e. |y0| < 2^-16 |a| (both normal);
+        // |y0| < 2^-15 |a| is a superset of that (it sends a few more lanes to the scalar function, whose result the fast path
+        // equals wherever it is valid) and costs a multiply and a compare instead of two exponent extractions, a subtract and a compare
+        rare |= absD(y0[e]) < absD(a[e]) * 0x1p-15;
     }
     // lanes of a wave sit on neighbouring latitudes: usually every argument needs the same kernel
     bool odd = false, even = false;
@@ -149,16 +172,28 @@ template <int N> TPG_DEV void atan_b(const double (&x)[N], double (&out)[N])
 // negations of each other; a zero difference is +0 either way).
 // Looked up per lane from LDS (3 ds_read_b128) instead of selects over the unused candidates.
 struct AtanRow { double p, q, r, s, hi, lo; };
-#define TPG_ATAN_TABLE_DOUBLES 30
+// The interval is looked up too (round 3): the four thresholds 0.4375, 0.6875, 1.1875, 2.4375 have zero low words and high words
+// that are multiples of 2^15, so |x| >= T  <=>  (high word of |x|) >> 15 >= (high word of T) >> 15, and the 81 values
+// u = clamp(((hi >> 15) & 0xFFFF) - 0x7FB7, 0, 80) cover all five intervals (u = 0: below 0.4375 ... u = 80: from 2.4375 up, +Inf
+// and NaN included -- a NaN argument gives NaN through any row).  lut[u] = byte offset of the row: 3 integer instructions and one
+// ds_read_u8 instead of 4 compares + 4 selects.  The LUT sits behind the 30 row doubles (12 more doubles per copy).
+#define TPG_ATAN_ROWS_DOUBLES 30
+#define TPG_ATAN_TABLE_DOUBLES 42
+// LUT packed four bytes to a word: byte b = row offset of u = b (0 | 1..20 -> 48 | 21..46 -> 96 | 47..79 -> 144 | 80.. -> 192)
+__device__ const unsigned kAtanLutWords[24] = {
+    0x30303000u, 0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u, 0x60606030u, 0x60606060u, 0x60606060u,
+    0x60606060u, 0x60606060u, 0x60606060u, 0x90606060u, 0x90909090u, 0x90909090u, 0x90909090u, 0x90909090u,
+    0x90909090u, 0x90909090u, 0x90909090u, 0x90909090u, 0xC0C0C0C0u, 0xC0C0C0C0u, 0xC0C0C0C0u, 0xC0C0C0C0u };
 TPG_DEV void atan_table_init(double* tab, int tid)
 {
+    if (tid < 24) reinterpret_cast<unsigned*>(tab + TPG_ATAN_ROWS_DOUBLES)[tid] = kAtanLutWords[tid];
     const double rows[5][6] = {
         { 1.0, 0.0, 1.0, 0.0, 0.0, 0.0 },                                        // [0, 0.4375): direct
         { 2.0, 1.0, 2.0, 1.0, 0x1.dac670561bb4fp-2, 0x1.a2b7f222f65e2p-56 },     // [0.4375, 0.6875): (2x-1)/(2+x), atan(0.5)
         { 1.0, 1.0, 1.0, 1.0, 0x1.921fb54442d18p-1, 0x1.1a62633145c07p-55 },     // [0.6875, 1.1875): (x-1)/(x+1),  atan(1)
         { 1.0, 1.5, 1.0, 1.5, 0x1.f730bd281f69bp-1, 0x1.007887af0cbbdp-56 },     // [1.1875, 2.4375): (x-1.5)/(1+1.5x), atan(1.5)
         { 0.0, 1.0, 0.0, 1.0, kPio2Hi, kPio2Lo } };                              // [2.4375, inf]:   -1/x, pi/2
-    if (tid < TPG_ATAN_TABLE_DOUBLES) tab[tid] = rows[tid / 6][tid % 6];
+    if (tid < TPG_ATAN_ROWS_DOUBLES) tab[tid] = rows[tid / 6][tid % 6];
 }
 
 // atan(x), all x, with the interval constants taken from the LDS table (see atan_b for the
@@ -170,9 +205,10 @@ template <int N, bool FINITE = false> TPG_DEV void atan_tab_b(const double (&x)[
     double t[N], hi[N], lo[N], s[N];
     TPG_UNROLL for (int e = 0; e < N; ++e) {
         const double ax = absD(x[e]);
-        int off = 0;                                    // doubles into the table: a select, not a sum and a multiply
-        off = ax >= 0.4375 ? 6 : off; off = ax >= 0.6875 ? 12 : off; off = ax >= 1.1875 ? 18 : off; off = ax >= 2.4375 ? 24 : off;
-        const AtanRow row = *reinterpret_cast<const AtanRow*>(tab + off);
+        int u = (int)__builtin_amdgcn_ubfe((unsigned)__double2hiint(x[e]), 15u, 16u) - 0x7FB7;     // bits 15..30 of the high word: sign dropped
+        u = u < 0 ? 0 : (u > 80 ? 80 : u);
+        const unsigned off = reinterpret_cast<const unsigned char*>(tab + TPG_ATAN_ROWS_DOUBLES)[u];   // bytes
+        const AtanRow row = *reinterpret_cast<const AtanRow*>(reinterpret_cast<const char*>(tab) + off);
         hi[e] = row.hi; lo[e] = row.lo;
         const double axn = (!FINITE && ax > 0x1p1000) ? 0x1p1000 : ax;      // NaN stays NaN (and selects the direct row)
         const double num = row.p * axn - row.q;

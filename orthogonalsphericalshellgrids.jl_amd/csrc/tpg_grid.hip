@@ -269,6 +269,19 @@ __device__ __forceinline__ void put(const OutPtrs& o, int q, long long off, doub
     if (NT) __builtin_nontemporal_store((T)v, p); else *p = (T)v;
 }
 
+// The tile kernel addresses its stores as (uniform base pointer) + (32-bit BYTE offset in a VGPR): the saddr form of
+// global_store takes exactly that, so the 20 stores of a cell share two offset registers instead of each paying a 64-bit
+// v_lshl_add_u64 for its own address (round 3).  Valid while one array is smaller than 4 GiB -- the launcher checks.
+template <typename T, bool NT = false>
+__device__ __forceinline__ void put32(const OutPtrs& o, int q, unsigned boff, double v)
+{
+    // the empty asm keeps the zero-extension of the offset next to its store: hoisted and shared as a 64-bit pair, it would no
+    // longer match the saddr addressing pattern and every store would pay a 64-bit add again
+    asm volatile("" : "+v"(boff));
+    T* p = reinterpret_cast<T*>(static_cast<char*>(o.p[q]) + boff);
+    if (NT) __builtin_nontemporal_store((T)v, p); else *p = (T)v;
+}
+
 // ---- K1: interior cells ------------------------------------------------------------------------
 template <typename T, bool NT>
 __global__ __launch_bounds__(256) void k_cells(GridK g, OutPtrs o)
@@ -502,7 +515,7 @@ enum { L_FC = 0, L_CC = 3, L_FF = 9, L_CF = 15 };    // field bases: FC(lam,a,ca
 template <int N>
 __device__ __forceinline__ void hav_batch(const Nb (&X)[N], const Nb (&Y)[N], double Rad, double (&d)[N])
 {
-    double hp[N], hl[N], s1[N], s2[N], rm[N], as[N];
+    double hp[N], hl[N], s1[N], s2[N], rt[N], rm[N], as[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) {
         double dl = (Y[e].lam - X[e].lam) * kDeg2Rad;
@@ -520,12 +533,14 @@ __device__ __forceinline__ void hav_batch(const Nb (&X)[N], const Nb (&Y)[N], do
 #pragma unroll
     for (int e = 0; e < N; ++e) {
         double h = s1[e] * s1[e] + X[e].ca * Y[e].ca * (s2[e] * s2[e]);
-        const double r = sqrt_nr(h);              // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles)
-        rm[e] = !(r >= 1.0) ? r : 1.0;        // min(r, 1) with NaN kept: one compare
+        rt[e] = sqrt_nr(h);                       // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles)
+        // min(r, 1) as ONE v_min_f64.  The reference's min keeps a NaN; minnum drops it (-> 1.0), but 1.0 is outside the fast domain
+        // of asin_small_b (|x| < 0.5), so such a lane raises `rare` and the fallback below recomputes the NaN-keeping min from rt
+        rm[e] = __builtin_fmin(rt[e], 1.0);
     }
     if (tpgb::asin_small_b<N>(rm, as)) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) as[e] = asinD(rm[e]);
+        for (int e = 0; e < N; ++e) as[e] = asinD(!(rt[e] >= 1.0) ? rt[e] : 1.0);
     }
 #pragma unroll
     for (int e = 0; e < N; ++e) d[e] = 2 * (Rad * as[e]);
@@ -554,8 +569,8 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
     if (i > g.Nx + 1) i = g.Nx + 1;
     const double Rad = g.R;
     const bool active_row = s <= g.jm_hi;                                    // rows past the band: idle waves
-    const long long col = (long long)(i + g.Hx - 1);
-    auto rowoff = [&](int j) -> long long { return col + (long long)g.sx * (j - g.jstart + g.Hy); };
+    const unsigned col = (unsigned)(i + g.Hx - 1);
+    auto rowoff = [&](int j) -> unsigned { return (col + (unsigned)g.sx * (unsigned)(j - g.jstart + g.Hy)) * (unsigned)sizeof(T); };   // bytes
 
     // ---- phase 1: one point set per thread
     Step4 q;
@@ -575,14 +590,14 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         // coordinates: rows p >= 1 emit CC/FC(s) and FF/CF(s+1); the first tile's apron row emits FF/CF(jm_lo)
         if (col_emit) {
             if (p >= 1 && s >= g.jm_lo) {
-                long long off = rowoff(s);
-                put<T, NT>(o, TPG_LAMBDA_FC, off, q.lam[0]); put<T, NT>(o, TPG_PHI_FC, off, q.phi[0]);
-                put<T, NT>(o, TPG_LAMBDA_CC, off, q.lam[1]); put<T, NT>(o, TPG_PHI_CC, off, q.phi[1]);
+                unsigned off = rowoff(s);
+                put32<T, NT>(o, TPG_LAMBDA_FC, off, q.lam[0]); put32<T, NT>(o, TPG_PHI_FC, off, q.phi[0]);
+                put32<T, NT>(o, TPG_LAMBDA_CC, off, q.lam[1]); put32<T, NT>(o, TPG_PHI_CC, off, q.phi[1]);
             }
             if ((p >= 1 || ty == 0) && s + 1 >= g.jm_lo && s + 1 <= g.jm_hi) {
-                long long off1 = rowoff(s + 1);
-                put<T, NT>(o, TPG_LAMBDA_FF, off1, q.lam[2]); put<T, NT>(o, TPG_PHI_FF, off1, q.phi[2]);
-                put<T, NT>(o, TPG_LAMBDA_CF, off1, q.lam[3]); put<T, NT>(o, TPG_PHI_CF, off1, q.phi[3]);
+                unsigned off1 = rowoff(s + 1);
+                put32<T, NT>(o, TPG_LAMBDA_FF, off1, q.lam[2]); put32<T, NT>(o, TPG_PHI_FF, off1, q.phi[2]);
+                put32<T, NT>(o, TPG_LAMBDA_CF, off1, q.lam[3]); put32<T, NT>(o, TPG_PHI_CF, off1, q.phi[3]);
             }
         }
         double (*L)[R][64] = lds.v;
@@ -611,8 +626,8 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
                         Nb{ L[L_FC + 0][rb - 1][lane], L[L_FC + 1][rb - 1][lane], L[L_FC + 2][rb - 1][lane] } };
             double dd2[2];
             hav_batch<2>(X, Y, Rad, dd2);
-            if (sa >= g.jm_lo) put<T, NT>(o, TPG_DY_FF, rowoff(sa), dd2[0]);
-            if (two && sb >= g.jm_lo) put<T, NT>(o, TPG_DY_FF, rowoff(sb), dd2[1]);
+            if (sa >= g.jm_lo) put32<T, NT>(o, TPG_DY_FF, rowoff(sa), dd2[0]);
+            if (two && sb >= g.jm_lo) put32<T, NT>(o, TPG_DY_FF, rowoff(sb), dd2[1]);
         }
         return;
     }
@@ -622,7 +637,7 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
     //      live set stays under 128 VGPRs (4 waves/SIMD supply the ILP; batches of 2 suffice)
     double (*L)[R][64] = lds.v;
     const int pm = p - 1, le = lane + 1, lw = lane - 1;
-    const long long off = rowoff(s);
+    const unsigned off = rowoff(s);
 
     // 2 spherical quadrilaterals first (unit vectors only): Az_cc from FF points, Az_ff from CC points
 #pragma unroll
@@ -650,7 +665,7 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         A += 2 * at[1];
         A += 2 * at[2];
         A += 2 * at[3];
-        put<T, NT>(o, k == 0 ? TPG_AZ_CC : TPG_AZ_FF, off, (A / 2) * (Rad * Rad));
+        put32<T, NT>(o, k == 0 ? TPG_AZ_CC : TPG_AZ_FF, off, (A / 2) * (Rad * Rad));
     }
 
     // 8 haversines in pairs; operand e = (x point, y point), each {lam, a, ca}
@@ -675,12 +690,12 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         hav_batch<1>(X, Y, Rad, dd1);
         d[6] = dd1[0];
     }
-    put<T, NT>(o, TPG_DX_CC, off, d[0]); put<T, NT>(o, TPG_DX_FC, off, d[1]);
-    put<T, NT>(o, TPG_DX_CF, off, d[2]); put<T, NT>(o, TPG_DX_FF, off, d[3]);
-    put<T, NT>(o, TPG_DY_CC, off, d[4]); put<T, NT>(o, TPG_DY_FC, off, d[5]);
-    put<T, NT>(o, TPG_DY_CF, off, d[6]);
-    put<T, NT>(o, TPG_AZ_FC, off, d[5] * d[1]);
-    put<T, NT>(o, TPG_AZ_CF, off, d[6] * d[2]);
+    put32<T, NT>(o, TPG_DX_CC, off, d[0]); put32<T, NT>(o, TPG_DX_FC, off, d[1]);
+    put32<T, NT>(o, TPG_DX_CF, off, d[2]); put32<T, NT>(o, TPG_DX_FF, off, d[3]);
+    put32<T, NT>(o, TPG_DY_CC, off, d[4]); put32<T, NT>(o, TPG_DY_FC, off, d[5]);
+    put32<T, NT>(o, TPG_DY_CF, off, d[6]);
+    put32<T, NT>(o, TPG_AZ_FC, off, d[5] * d[1]);
+    put32<T, NT>(o, TPG_AZ_CF, off, d[6] * d[2]);
 }
 
 // ---- K2: halo cells of the 20 arrays ------------------------------------------------------------
@@ -801,7 +816,8 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
     const int nrows = g.jm_hi - g.jm_lo + 1;
     const int tiles_x = (g.Nx + 61) / 62;
     const int tiles_y = (nrows + (R - 1) - 1) / (R - 1);
-    if (cfg.cells_variant == 3 && tiles_y <= 65535) {          // tile rows ride on gridDim.y
+    const bool offsets32 = (unsigned long long)g.sx * (unsigned long long)(g.jend - g.jstart + 1 + 2 * g.Hy) * sizeof(T) < (1ull << 32);
+    if (cfg.cells_variant == 3 && tiles_y <= 65535 && offsets32) {     // tile rows ride on gridDim.y; stores use 32-bit byte offsets
         dim3 gridt((unsigned)tiles_x, (unsigned)tiles_y);
         if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x);
         else    hipLaunchKernelGGL((k_cells_tile<T, false, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x);
