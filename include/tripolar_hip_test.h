@@ -43,7 +43,8 @@ int tpg_fill_synthetic(void *field, uint64_t seed, double halo_sentinel,
  * elementary functions (which = 0 sin, 1 cos, 2 sind, 3 cosd, 4 tand, 5 atan, 6 asin, 7 asinh, 8 sinh,
  * 9 cosh, 10 acos; 20 sqrt_nr(x), 21 div_nr over pairs x = (a0, b0, a1, b1, ...): the unscaled square root and
  * division of the metric kernel) or one of the straight-line batch forms used by the metric kernel (100 sin_small, 101 cos,
- * 102 atan, 103 atan_tab, 104 atan_small, 105 asin_small, 106 sind / 107 cosd of sincosd) on n device
+ * 102 atan, 103 atan_tab, 104 atan_small, 105 asin_small, 106 sind / 107 cosd of sincosd, 108 sind / 109 cosd of the latitude form
+ * sincosd_lat, 110 cos of a latitude in radians) on n device
  * doubles x -> y; rare[i] (int32) = 1 where a batch form reports "outside my fast domain".
  * These stand in for Julia Base / Distances arithmetic. */
 int tpg_math_probe(int which, const void *x, void *y, void *rare, long long n, void *stream);

@@ -114,6 +114,36 @@ template <int N> TPG_DEV bool cos_b(const double (&a)[N], double (&out)[N])
     return rare;
 }
 
+// cos(a) for a = deg2rad(latitude), |a| <= pi/2 (+ rounding): the Cody-Waite quotient n = rint(a 2/pi) is -1, 0 or +1, so the
+// quadrant logic of cos_b -- convert to int, test bit 0, test bit 1 of n + 1 -- collapses to two compares of the quotient itself:
+// n = 0 -> kcos(y), n = +1 -> -ksin(y), n = -1 -> +ksin(y).  Same reduction, same kernels, same bits as cos_b / tpgm::cosD.
+// rare: |n| > 1 (not a latitude), or the reduction would need its 2nd iteration (see cos_b) -> caller uses tpgm::cosD.
+template <int N> TPG_DEV bool cos_lat_b(const double (&a)[N], double (&out)[N])
+{
+    double fn[N], y0[N], y1[N], S[N], C[N];
+    bool rare = false;
+    TPG_UNROLL for (int e = 0; e < N; ++e) fn[e] = __builtin_rint(a[e] * kInvPio2);
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        double r = a[e] - fn[e] * kPio2_1;
+        double w = fn[e] * kPio2_1t;
+        y0[e] = r - w;
+        y1[e] = (r - y0[e]) - w;
+        rare |= absD(y0[e]) < absD(a[e]) * 0x1p-15;
+        rare |= !(absD(fn[e]) <= 1.0);
+    }
+    bool odd = false, even = false;
+    TPG_UNROLL for (int e = 0; e < N; ++e) { odd |= fn[e] != 0.0; even |= fn[e] == 0.0; }
+    TPG_UNROLL for (int e = 0; e < N; ++e) { S[e] = 0.0; C[e] = 0.0; }
+    if (__any(odd)) ksin_b<N>(y0, y1, S);
+    if (__any(even)) kcos_b<N>(y0, y1, C);
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        const double v = (fn[e] != 0.0) ? S[e] : C[e];
+        const double nv = -v;
+        out[e] = (fn[e] > 0.0) ? nv : v;
+    }
+    return rare;
+}
+
 // atan(x), all x (finite, +-Inf; NaN -> NaN).  The scalar early-outs are redundant value-wise:
 //  |x| < 2^-27: t - t (s1+s2) with s1+s2 ~ t^2/3 < 2^-55 rounds to t;
 //  |x| >= 2^66 (and Inf): t = -1/|x| is below half an ulp of pi/2, the formula gives RN(hi + lo) = hi.
@@ -334,6 +364,36 @@ template <int N> TPG_DEV void sincosd_b(const double (&x)[N], double (&sn)[N], d
         const double fc = codd[e] ? fodd : feven;
         cs[e] = fc * bc;
     }
+}
+
+// sind / cosd pairs for latitudes, |x| <= 90: of sincosd_b's eight octant compares only the first of each set can be true, 90 m is
+// 0 or 90, the sine carries the sign of x and the cosine is never negated (90 - r >= +0):
+//    r < 45 (sind) / r <= 45 (cosd):  sind = sign(x) ksin(r),        cosd = kcos(r)
+//    otherwise:                        sind = sign(x) kcos(90 - r),   cosd = ksin(90 - r)
+// -- the same reduction t = |90 m - r|, the same kernels and therefore the same bits as sincosd_b / tpgm::sind, cosd.
+// rare: some |x| > 90 or NaN -> caller uses sincosd_b.
+template <int N> TPG_DEV bool sincosd_lat_b(const double (&x)[N], double (&sn)[N], double (&cs)[N])
+{
+    double h[N], l[N], S[N], C[N];
+    bool s1[N], c1[N], rare = false;
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        const double r = absD(x[e]);
+        rare |= !(r <= 90.0);
+        s1[e] = r >= 45.0; c1[e] = r > 45.0;
+        const double d = (s1[e] ? 90.0 : 0.0) - r;
+        const double t = absD(d);
+        const double hh = t * kDeg2Rad;
+        l[e] = fmaD(t, kDeg2Rad, -hh) + t * kDeg2RadLo;
+        h[e] = hh;
+    }
+    ksin_b<N>(h, l, S);
+    kcos_b<N>(h, l, C);
+    TPG_UNROLL for (int e = 0; e < N; ++e) {
+        const double bs = s1[e] ? C[e] : S[e];
+        sn[e] = csign(1.0, x[e]) * bs;
+        cs[e] = c1[e] ? S[e] : C[e];
+    }
+    return rare;
 }
 
 // fmod(x, 360) for 0 <= x < 720 (the second application in ((l % 360) + 360) % 360: l % 360 is in (-360, 360))

@@ -469,14 +469,16 @@ __device__ __forceinline__ void points_fast2(const GridK& g, const LaneConst& lc
 #pragma unroll
     for (int h = 0; h < 4; h += 2) {
         double aa[2] = { s.a[h], s.a[h + 1] }, cc2[2];
-        if (tpgb::cos_b<2>(aa, cc2)) { cc2[0] = cosD(aa[0]); cc2[1] = cosD(aa[1]); }
+        if (tpgb::cos_lat_b<2>(aa, cc2)) { cc2[0] = cosD(aa[0]); cc2[1] = cosD(aa[1]); }      // a = deg2rad(latitude)
         s.ca[h] = cc2[0]; s.ca[h + 1] = cc2[1];
     }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {        // h = 0: CC (lam[1], phi[1]);  h = 1: FF (lam[2], phi[2])
-        double ang2[2] = { s.lam[1 + h], s.phi[1 + h] }, sn2[2], cs2[2];
-        tpgb::sincosd_b<2>(ang2, sn2, cs2);
-        sn[2 * h] = sn2[0]; sn[2 * h + 1] = sn2[1]; cs[2 * h] = cs2[0]; cs[2 * h + 1] = cs2[1];
+    {   // unit vectors of CC (lam[1], phi[1]) and FF (lam[2], phi[2]): the two longitudes through the general form, the two latitudes
+        // through the |x| <= 90 form; sn / cs index = 2 * point + (0 longitude, 1 latitude)
+        double lon[2] = { s.lam[1], s.lam[2] }, lat[2] = { s.phi[1], s.phi[2] }, sl[2], cl[2], sp[2], cp[2];
+        tpgb::sincosd_b<2>(lon, sl, cl);
+        if (tpgb::sincosd_lat_b<2>(lat, sp, cp)) tpgb::sincosd_b<2>(lat, sp, cp);
+        sn[0] = sl[0]; cs[0] = cl[0]; sn[1] = sp[0]; cs[1] = cp[0];
+        sn[2] = sl[1]; cs[2] = cl[1]; sn[3] = sp[1]; cs[3] = cp[1];
     }
     s.X[0] = cs[0] * cs[1]; s.Y[0] = sn[0] * cs[1]; s.Z[0] = sn[1];      // CC
     s.X[1] = cs[2] * cs[3]; s.Y[1] = sn[2] * cs[3]; s.Z[1] = sn[3];      // FF

@@ -13,7 +13,8 @@ namespace {
 
 enum { F_SIN, F_COS, F_SIND, F_COSD, F_TAND, F_ATAN, F_ASIN, F_ASINH, F_SINH, F_COSH, F_ACOS,          // scalar
        F_SQRT_NR = 20, F_DIV_NR = 21,                                                          // unscaled sqrt / division
-       B_SIN_SMALL = 100, B_COS, B_ATAN, B_ATAN_TAB, B_ATAN_SMALL, B_ASIN_SMALL, B_SIND, B_COSD }; // batch
+       B_SIN_SMALL = 100, B_COS, B_ATAN, B_ATAN_TAB, B_ATAN_SMALL, B_ASIN_SMALL, B_SIND, B_COSD,      // batch
+       B_SIND_LAT, B_COSD_LAT, B_COS_LAT };                                                            // latitude-domain batch forms
 
 __global__ __launch_bounds__(256) void k_probe(int which, const double* __restrict__ x, double* __restrict__ y,
                                                int* __restrict__ rare, long long n)
@@ -38,6 +39,9 @@ __global__ __launch_bounds__(256) void k_probe(int which, const double* __restri
         case B_ASIN_SMALL: r = tpgb::asin_small_b<4>(a, o); break;
         case B_SIND:       tpgb::sincosd_b<4>(a, o, o2); break;
         case B_COSD:       tpgb::sincosd_b<4>(a, o2, o); break;
+        case B_SIND_LAT:   r = tpgb::sincosd_lat_b<4>(a, o, o2); break;
+        case B_COSD_LAT:   r = tpgb::sincosd_lat_b<4>(a, o2, o); break;
+        case B_COS_LAT:    r = tpgb::cos_lat_b<4>(a, o); break;
         default: return;
         }
         for (int e = 0; e < 4; ++e) if (base + e < n) { y[base + e] = o[e]; rare[base + e] = r ? 1 : 0; }

@@ -90,6 +90,15 @@ BATCH = [
                                        np.array([0.0, -0.0, 359.99999999999994])]), None),
     (107, 3, lambda r: np.concatenate([r.uniform(-359.9, 359.9, N), np.arange(-345, 346, 15.0),
                                        np.array([0.0, -0.0, 359.99999999999994])]), None),
+    # latitude-domain forms (round 3): sind / cosd for |x| <= 90, cos for |a| <= pi/2 -- flagged `rare` outside
+    (108, 2, lambda r: np.concatenate([r.uniform(-95, 95, N), np.arange(-120, 121, 15.0), 45 + r.uniform(-1e-9, 1e-9, 4000),
+                                       np.array([0.0, -0.0, 90.0, -90.0, 45.0, -45.0, 89.99999999999999, 5e-324, 1e-310])]),
+     lambda x: np.abs(x) <= 90.0),
+    (109, 3, lambda r: np.concatenate([r.uniform(-95, 95, N), np.arange(-120, 121, 15.0), 45 + r.uniform(-1e-9, 1e-9, 4000),
+                                       np.array([0.0, -0.0, 90.0, -90.0, 45.0, -45.0, 89.99999999999999, 5e-324, 1e-310])]),
+     lambda x: np.abs(x) <= 90.0),
+    (110, 1, lambda r: np.concatenate([r.uniform(-1.7, 1.7, N), np.pi / 2 + r.uniform(-1e-4, 1e-4, 4000), np.pi / 4 + r.uniform(-1e-9, 1e-9, 4000),
+                                       np.array([0.0, -0.0, np.pi / 2, -np.pi / 2, np.pi / 4, -np.pi / 4, 2.4, -2.4, 3.2])]), "flag"),
 ]
 
 
@@ -106,7 +115,7 @@ def test_batch_form_equals_scalar(osg, gpu, bid, sid, gen, domain):
     if domain == "flag":                               # cos_b: wherever the group is not flagged the bits must match
         bad = ~ok & ~rare
         assert not bad.any(), f"{bad.sum()} unflagged mismatches, e.g. x={x[bad][:3]!r}"
-        assert rare.mean() < 0.02
+        assert rare.mean() < (0.02 if bid == 101 else 0.12)      # cos_lat_b also flags |a| beyond a latitude (|n| > 1)
         return
     inside = domain(x)
     grp = inside.reshape(-1, 4).all(axis=1).repeat(4)  # a group is fast iff all 4 arguments are inside
