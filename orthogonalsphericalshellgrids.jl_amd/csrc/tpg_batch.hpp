@@ -399,16 +399,16 @@ template <int N> TPG_DEV bool sincosd_lat_b(const double (&x)[N], double (&sn)[N
 // fmod(x, 360) for 0 <= x < 720 (the second application in ((l % 360) + 360) % 360: l % 360 is in (-360, 360))
 TPG_DEV double fmod360_pos(double x)
 {
-    const double w = x - 360.0;
-    return x < 360.0 ? x : w;
+    // x - (x >= 360 ? 360 : 0): both constants have a zero low word, so the select is ONE v_cndmask on the high word, and x - 0.0 = x
+    // for every x (signed zeros included)
+    return x - __hiloint2double(!(x < 360.0) ? 0x40768000 : 0, 0);
 }
 
 // exact fmod(x, 360) for |x| < 720 (select form of tpgm::fmod360)
 TPG_DEV double fmod360_small(double x)
 {
     const double ax = absD(x);
-    const double w = csign(ax - 360.0, x);
-    return ax < 360.0 ? x : w;
+    return csign(ax - __hiloint2double(!(ax < 360.0) ? 0x40768000 : 0, 0), x);       // csign(|x| - 0, x) = x
 }
 
 }  // namespace tpgb

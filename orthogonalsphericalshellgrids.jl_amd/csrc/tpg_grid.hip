@@ -517,7 +517,8 @@ enum { L_FC = 0, L_CC = 3, L_FF = 9, L_CF = 15 };    // field bases: FC(lam,a,ca
 template <int N>
 __device__ __forceinline__ void hav_batch(const Nb (&X)[N], const Nb (&Y)[N], double Rad, double (&d)[N])
 {
-    double hp[N], hl[N], s1[N], s2[N], rt[N], rm[N], as[N];
+    double hp[N], hl[N], s1[N], s2[N], hh[N], rt[N], rm[N], as[N];
+    bool zero = false;
 #pragma unroll
     for (int e = 0; e < N; ++e) {
         double dl = (Y[e].lam - X[e].lam) * kDeg2Rad;
@@ -535,7 +536,16 @@ __device__ __forceinline__ void hav_batch(const Nb (&X)[N], const Nb (&Y)[N], do
 #pragma unroll
     for (int e = 0; e < N; ++e) {
         double h = s1[e] * s1[e] + X[e].ca * Y[e].ca * (s2[e] * s2[e]);
-        rt[e] = sqrt_nr(h);                       // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles)
+        hh[e] = h;
+        zero |= h == 0.0;
+        rt[e] = sqrt_nr<true>(h);                 // h = 0 or >= ~1e-34 (squares of half-differences of O(1) doubles); h = 0 patched below
+    }
+    if (zero) {                                   // coincident points (pole-adjacent edges): the unscaled square root needs x > 0
+#pragma unroll
+        for (int e = 0; e < N; ++e) rt[e] = sqrt_nr(hh[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
         // min(r, 1) as ONE v_min_f64.  The reference's min keeps a NaN; minnum drops it (-> 1.0), but 1.0 is outside the fast domain
         // of asin_small_b (|x| < 0.5), so such a lane raises `rare` and the fallback below recomputes the NaN-keeping min from rt
         rm[e] = __builtin_fmin(rt[e], 1.0);
