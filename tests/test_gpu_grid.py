@@ -235,3 +235,29 @@ def test_orthogonality_of_the_device_built_grid(osg, gpu):
     mask = ((abs(L - 75) < 5) & (abs(35 - P) < 5)) | ((abs(L - 255) < 5) & (abs(35 - P) < 5)) | (P < -78)
     ang = torch.where(mask, torch.zeros_like(ang), ang)
     assert float(ang.max()) < 2.0 and float(ang.min()) > -2.0
+
+
+def test_arrays_beyond_4_GiB_take_the_64_bit_offsets(osg, gpu):
+    """The tile kernel addresses its stores with 32-bit byte offsets (saddr form), valid while ONE array is below 4 GiB; the launcher
+    must send larger arrays to the thread-per-cell kernel with 64-bit offsets.  16384 x 32768 Float64: 4.30 GB per array, 86 GB for
+    the 20.  Checked against latitude BANDS of the same grid built by the tile kernel (their arrays are small; band builds are
+    bit-exact against the oracle in test_latitude_bands_equal_slices_of_the_global_grid): rows at the south end, across the 4 GiB
+    mark, and at the north fold."""
+    size, halo = (16384, 32768, 1), (4, 4, 1)
+    Nx, Ny = size[0], size[1]
+    assert (Nx + 8) * (Ny + 8) * 8 >= 1 << 32
+    free, _ = torch.cuda.mem_get_info(gpu)
+    if free < 100e9:
+        pytest.skip("needs 100 GB of free HBM")
+    big = osg.TripolarGrid(osg.GPU(0), torch.float64, size=size, halo=halo)
+    R = 512                                                            # 64 rows per band
+    row_4gib = (1 << 32) // ((Nx + 8) * 8) - 4 + 1                     # the global row whose cells straddle byte offset 2^32: 32749
+    assert 64 * (R - 1) < row_4gib <= Ny                               # ... lies in the northernmost band, below the fold rows
+    for r in (0, R // 2 - 1, R - 1):
+        band = osg.TripolarGrid(osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=r), torch.float64, size=size, halo=halo)
+        j0, j1 = band.jrange
+        assert (j0, j1) == (1 + 64 * r, 64 * (r + 1))
+        for name in osg._lib.ARRAY_NAMES:
+            assert torch.equal(getattr(band, name), getattr(big, name)[j0 - 1:j1 + 2 * halo[1]]), (r, name)
+    del big
+    torch.cuda.empty_cache()
