@@ -521,9 +521,10 @@ __device__ __forceinline__ void hav_batch(const Nb (&X)[N], const Nb (&Y)[N], do
     bool zero = false;
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-        double dl = (Y[e].lam - X[e].lam) * kDeg2Rad;
+        // (d lambda * deg2rad) / 2 as ONE product with deg2rad / 2: halving is exact and rounding is scale-invariant (no underflow:
+        // a difference of two longitudes is 0 or >= ~1e-14), so RN(x c) / 2 = RN(x (c / 2)) bit for bit
         double dp = Y[e].a - X[e].a;
-        hp[e] = dp / 2; hl[e] = dl / 2;
+        hp[e] = dp / 2; hl[e] = (Y[e].lam - X[e].lam) * (kDeg2Rad * 0.5);
     }
     if (tpgb::sin_small_b<N>(hp, s1)) {
 #pragma unroll
@@ -555,7 +556,7 @@ __device__ __forceinline__ void hav_batch(const Nb (&X)[N], const Nb (&Y)[N], do
         for (int e = 0; e < N; ++e) as[e] = asinD(!(rt[e] >= 1.0) ? rt[e] : 1.0);
     }
 #pragma unroll
-    for (int e = 0; e < N; ++e) d[e] = 2 * (Rad * as[e]);
+    for (int e = 0; e < N; ++e) d[e] = (2 * Rad) * as[e];      // 2 (R asin) = (2 R) asin bit for bit: doubling is exact (2 R: wave-uniform)
 }
 
 template <typename T, bool NT, int R>
@@ -673,11 +674,13 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
             tt[0] = tri_tan(a, b, c); tt[1] = tri_tan(a, b, dd); tt[2] = tri_tan(a, c, dd); tt[3] = tri_tan(b, c, dd);
             tpgb::atan_b<4>(tt, at);
         }
-        double A = 2 * at[0];
-        A += 2 * at[1];
-        A += 2 * at[2];
-        A += 2 * at[3];
-        put32<T, NT>(o, k == 0 ? TPG_AZ_CC : TPG_AZ_FF, off, (A / 2) * (Rad * Rad));
+        // (2 t0 + 2 t1 + 2 t2 + 2 t3) / 2, summed left to right, is t0 + t1 + t2 + t3 summed left to right: doubling and halving are
+        // exact and commute with every rounding (no overflow / underflow at these magnitudes) -- 5 multiplications less per quadrilateral
+        double A = at[0];
+        A += at[1];
+        A += at[2];
+        A += at[3];
+        put32<T, NT>(o, k == 0 ? TPG_AZ_CC : TPG_AZ_FF, off, A * (Rad * Rad));
     }
 
     // 8 haversines in pairs; operand e = (x point, y point), each {lam, a, ca}
