@@ -447,8 +447,16 @@ __device__ __forceinline__ void points_fast2(const GridK& g, const LaneConst& lc
     double x[4] = { lc.aslF * chC, lc.aslC * chC, lc.aslF * chF, lc.aslC * chF };          // :67
     double y[4] = { lc.aclF * shC, lc.aclC * shC, lc.aclF * shF, lc.aclC * shF };          // :68
     double q[4], rr[4], at1[4], at2[4];
+    // y / x through the unscaled division: both are products of finite table entries of moderate size (|x| is 0 on the two pole
+    // meridians, else >= ~1e-17; tests/test_gpu_math.py checks div_nr against IEEE on that range), so only a zero denominator needs the
+    // IEEE form (+-Inf) -- those lanes redo the division
+    bool zerox = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { q[k] = y[k] / x[k]; rr[k] = sqrt_nr<true>(y[k] * y[k] + x[k] * x[k]);   /* > 0: no pole below row Ny */ }
+    for (int k = 0; k < 4; ++k) { q[k] = div_nr(y[k], x[k]); zerox |= x[k] == 0.0; rr[k] = sqrt_nr<true>(y[k] * y[k] + x[k] * x[k]);   /* > 0: no pole below row Ny */ }
+    if (zerox) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = y[k] / x[k];
+    }
 #pragma unroll
     for (int h = 0; h < 4; h += 2) {
         double qa[2] = { q[h], q[h + 1] }, ra[2] = { rr[h], rr[h + 1] }, o1[2], o2[2];

@@ -139,6 +139,10 @@ def test_unscaled_sqrt_and_division_are_ieee_on_their_domain(osg, gpu):
     a = np.concatenate([r.uniform(-2, 2, N), 10.0 ** r.uniform(-60, 0.3, N), np.zeros(1000), r.uniform(-1, 1, N), -np.ones(N // 2)])
     b = np.concatenate([r.uniform(1e-3, 4, N) * r.choice([-1, 1], N), 10.0 ** r.uniform(-16, 0.6, N), r.uniform(0.5, 4, 1000),
                         r.uniform(0.7, 1.0, N), np.concatenate([10.0 ** r.uniform(0, 300, N // 2 - 3), np.array([2.0 ** 1000, 1.5 * 2.0 ** 1000, 1.0])])])
+    # ... and the Murray map's y / x (round 3): products of table entries, |x| from ~1e-17 (next to a pole meridian) to ~1e2
+    a2 = 10.0 ** r.uniform(-20, 3, N) * r.choice([-1, 1], N)
+    b2 = 10.0 ** r.uniform(-18, 3, N) * r.choice([-1, 1], N)
+    a, b = np.concatenate([a, a2, np.zeros(100)]), np.concatenate([b, b2, 10.0 ** r.uniform(-18, 3, 100)])
     xy = np.empty(2 * a.size)
     xy[0::2], xy[1::2] = a, b
     got, _ = probe(osg, gpu, 21, xy)
