@@ -448,21 +448,28 @@ __device__ __forceinline__ void points_fast2(const GridK& g, const LaneConst& lc
     double y[4] = { lc.aclF * shC, lc.aclC * shC, lc.aclF * shF, lc.aclC * shF };          // :68
     double q[4], rr[4], at1[4], at2[4];
     // y / x through the unscaled division: both are products of finite table entries of moderate size (|x| is 0 on the two pole
-    // meridians, else >= ~1e-17; tests/test_gpu_math.py checks div_nr against IEEE on that range), so only a zero denominator needs the
-    // IEEE form (+-Inf) -- those lanes redo the division
+    // meridians, else >= ~1e-17; tests/test_gpu_math.py checks div_nr against IEEE on that range).  A zero denominator is the one case
+    // that needs IEEE semantics (y / +-0 = +-Inf, and atan(+-Inf) = +-pi/2): those lanes are patched after the table atan, which can
+    // then take the FINITE form for every lane (no clamp of the argument; a NaN from div_nr(y, 0) just flows through the discarded lane).
     bool zerox = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { q[k] = div_nr(y[k], x[k]); zerox |= x[k] == 0.0; rr[k] = sqrt_nr<true>(y[k] * y[k] + x[k] * x[k]);   /* > 0: no pole below row Ny */ }
-    if (zerox) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) q[k] = y[k] / x[k];
-    }
 #pragma unroll
     for (int h = 0; h < 4; h += 2) {
         double qa[2] = { q[h], q[h + 1] }, ra[2] = { rr[h], rr[h + 1] }, o1[2], o2[2];
-        tpgb::atan_tab_b<2>(qa, o1, atab);
+        tpgb::atan_tab_b<2, true>(qa, o1, atab);
         tpgb::atan_tab_b<2, true>(ra, o2, atab);      // ra = sqrt(...) of finite table products
         at1[h] = o1[0]; at1[h + 1] = o1[1]; at2[h] = o2[0]; at2[h + 1] = o2[1];
+    }
+    if (zerox) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (x[k] == 0.0) {
+                // msun: atan(+-Inf) = +-(atanhi[3] + atanlo[3]) = +-pi/2 (the table row gives hi - ((-0 - lo) - t) = RN(hi + lo) = hi as well);
+                // 0 / 0 stays NaN
+                const double qq = y[k] / x[k];
+                at1[k] = (qq != qq) ? qq : csign(kPio2Hi, qq);
+            }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
