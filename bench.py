@@ -545,7 +545,7 @@ def main():
                 "frac": fill_bytes / (t_fill_kernel * 1e-3) / 1e9 / HBM_PEAK_GBPS if t_fill_kernel else None, "traffic": None,
                 "algorithmic_bytes_per_launch": fill_bytes, "launch_ms": t_fill_kernel,
                 "measured": "the kernel's own start/stop events, instrumented pass after the timed steps"}
-        flops = 2333.0 * NX * ny                                                # FP64 add/mul/fma (fma = 2) per cell, PMC-counted
+        flops = 2285.0 * NX * ny                                                # FP64 add/mul/fma (fma = 2) per cell, PMC-counted on the round-3 kernel (profiles/r03/cells_trims.txt)
         line["roofline_precompute"] = {
             "kernel": "tpg_build_grid (k_tables + k_cells_tile + k_halos)" + (", slowest rank" if world > 1 else ""), "bound": "hbm",
             "achieved": 160.0 * band_cells / (t_build * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -553,7 +553,7 @@ def main():
             "algorithmic_bytes_per_launch": 160 * band_cells,
             "fp64_tflops": flops / (t_build * 1e-3) / 1e12, "fp64_peak_tflops": FP64_VALU_PEAK_TFLOPS,
             "fp64_frac": flops / (t_build * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-            "note": "FP64-issue bound in practice (VALU busy 91 %%): ~%.1f TFLOP/s of the %.1f TFLOP/s vector FP64 peak at 2.33 kflop/cell (PMC count)"
+            "note": "FP64-issue bound in practice (VALU busy 91 %%): ~%.1f TFLOP/s of the %.1f TFLOP/s vector FP64 peak at 2.29 kflop/cell (PMC count)"
                     % (flops / (t_build * 1e-3) / 1e12, FP64_VALU_PEAK_TFLOPS)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
