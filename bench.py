@@ -372,6 +372,10 @@ def main():
         dog.set_phase("barrier after the first seam exchange")
         dist.barrier()
         dog.disarm()
+        # the rest of the run (warm-up, timed and instrumented steps: a few seconds) stays under a generous second deadline, so that
+        # an exchange that stalls LATER also ends with a diagnostic instead of the driver's kill
+        dog.seconds = max(10 * args.deadline, 600.0)
+        dog.arm("warm-up / timed / instrumented steps (a seam exchange after the first one never completed)")
 
     # ---- auxiliary measurements (not steps) ----------------------------------------------------------------------------------
     # Order: the config-5 block first (it allocates and frees 162 GB), the config-3 auxiliary block last.  Neither order changes
@@ -560,6 +564,7 @@ def main():
         print(json.dumps(line))          # ASCII-escaped: safe under any stdout encoding
     if world > 1:
         dist.barrier()
+        dog.disarm()
         if comm is not None:
             comm.destroy()
         dist.destroy_process_group()
