@@ -259,3 +259,61 @@ def test_two_plans_of_equal_geometry_in_flight_together(osg, oracle, gpu):
             jstart, jend = grid.jrange
             for f, g in zip(fs, sets[tag]):
                 assert np.array_equal(f.data.cpu().numpy(), g[:, jstart - 1:jend + 2 * Hy]), (tag, r, f.loc)
+
+
+def test_halo_fill_plan_marshals_the_one_call_distributed_fill(osg, gpu, monkeypatch):
+    """With an RcclComm on the architecture a HaloFillPlan issues ONE C call per batch, tpg_fill_halo_regions_distributed.  No second
+    RCCL rank exists on a one-GPU box, so the C function is replaced here by a recorder that checks every argument the plan hands
+    over (order, kinds, which seam buffers are present for which rank, geometry, the zipper tables on the last rank only) and runs
+    the local part of the fill; the C function itself runs against a real communicator in tools/rccl_selftest.py."""
+    import ctypes as C
+    from orthogonalsphericalshellgrids.jl_amd.distributed import RcclComm
+    lib = osg._lib.lib()
+    size, halo, R = (32, 24, 2), (4, 4, 1), 3
+    calls = []
+
+    def recorder(comm, rank, nranks, fields, nfields, xl, yl, sg, ss, sn, rs, rn, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream):
+        calls.append(dict(comm=comm, rank=rank, nranks=nranks, nfields=nfields, tables=(xl, yl, sg), bufs=(ss, sn, rs, rn),
+                          geom=(Nx, Ny, Nz, Hx, Hy, Hz), ft=ft, stream=stream, field0=fields[0]))
+        return lib.tpg_fill_halo_regions(fields, nfields, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, 1 if rank == nranks - 1 else 0, ft, stream)
+
+    monkeypatch.setattr(lib, "tpg_fill_halo_regions_distributed", recorder, raising=True)
+    for r in range(R):
+        comm = RcclComm(C.c_void_p(0xC0FFEE), r, R)
+        arch = osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=r, rccl_comm=comm)
+        grid = osg.TripolarGrid(arch, torch.float64, size=size, halo=halo)
+        fs = [osg.CenterField(grid), osg.XFaceField(grid), osg.YFaceField(grid)]
+        for f in fs:
+            f.data.copy_(torch.rand_like(f.data))
+        before = [f.data.clone() for f in fs]
+        plan = osg.halo_fill_plan(fs)
+        assert plan.is_distributed and all(p is None for _, _, p in plan._steps)          # one C call, no Python-side exchange object
+        with pytest.raises(ValueError):
+            plan.graph()                                                                    # a seam cannot be captured
+        calls.clear()
+        plan()
+        torch.cuda.synchronize()
+        assert len(calls) == 1
+        c = calls[0]
+        assert c["comm"].value == 0xC0FFEE and (c["rank"], c["nranks"], c["nfields"]) == (r, R, 3)
+        assert c["geom"] == (32, 8, 2, 4, 4, 1) and c["ft"] == 1 and c["field0"] == fs[0].data.data_ptr()
+        ss, sn, rs, rn = c["bufs"]
+        assert (ss is not None) == (r > 0) == (rs is not None) and (sn is not None) == (r < R - 1) == (rn is not None)
+        present = [b for b in c["bufs"] if b is not None]
+        assert len(set(present)) == len(present)                                           # four distinct message buffers
+        if r == R - 1:                                                                      # the zipper tables travel on the last rank only
+            xl, yl, sg = c["tables"]
+            assert list(xl) == [0, 1, 0] and list(yl) == [0, 0, 1] and list(sg) == [1, -1, -1]
+        else:
+            assert c["tables"] == (None, None, None)
+        # the local part ran: x halos are periodic images, and only the last rank's north halo was folded
+        for f, b in zip(fs, before):
+            assert torch.equal(f.data[:, :, :4], f.data[:, :, 32:36])
+            if r < R - 1:
+                assert torch.equal(f.data[:, 12:, 4:36], b[:, 12:, 4:36])
+    # pack-free plans hand over no buffers at all
+    comm = RcclComm(C.c_void_p(0xC0FFEE), 1, R)
+    grid = osg.TripolarGrid(osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=1, rccl_comm=comm), torch.float64, size=size, halo=halo)
+    calls.clear()
+    osg.halo_fill_plan([osg.CenterField(grid)], pack_free=True)()
+    assert calls[0]["bufs"] == (None, None, None, None)
