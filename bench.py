@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- TripolarGrid metric precompute + zipper halo fill at 1/10 deg x 75 levels on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak] [--exchange auto|monolithic|pipelined]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     (same thing, launcher supplied)
+  python bench.py --loopback [--loopback-bands R] [--loopback-band r]                          (1 GPU: the RCCL branch on one rank)
+
+`python bench.py --gpus N` with N > 1 and no launcher in the environment starts its own N workers: the parent -- which never
+imports torch and never touches a GPU -- spawns one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+MASTER_PORT=<free> set), relays rank 0's ONE JSON line to its stdout and exits with the children's status.
 
 One "step" = one pass of the hot path over one batch of synthetic input, resident in HBM:
   (1) tpg_build_grid : coordinates + 12 staggered metrics of this rank's latitude band
@@ -16,7 +21,15 @@ rows (N = 8: ny = 225, rank 7 owns the zipper; src/distributed_tripolar_grid.jl:
 point-to-point seams only.  `--scaling weak` keeps 1800 rows per rank of a 3600 x (1800 N) x 75 globe (not a BASELINE config).
 For N > 1 the halo fill (local fill + seam exchange) runs on a side stream beside the grid build on the main stream: the
 two touch disjoint memory.  Before the warm-up one fill runs under a host-side deadline: a stalled exchange ends the job
-with a one-line JSON diagnostic on stderr and a non-zero exit instead of a silent hang.
+with a one-line JSON diagnostic on stderr and a non-zero exit instead of a silent hang.  The seam exchange has two forms with
+identical results -- monolithic (pack all -> one RCCL group -> unpack all) and pipelined per field on a second stream
+(tpg_halo_exchange_y_pipelined) -- both are timed on every run (`exchange_ms_monolithic`, `exchange_ms_pipelined`, beside
+`link_floor_ms`); `--exchange auto` (default) runs the timed steps with whichever was faster (max over ranks).
+`--loopback` runs that whole N > 1 branch -- communicator bring-up under the watchdog, seam buffers, the one-call distributed
+fill in both forms, the side-stream overlap with the build, the instrumented passes -- on ONE GPU: a communicator of one rank
+whose south / north peer is the rank itself, for band r of a chain of R (default: band 3 of 8 = an interior band of BASELINE
+config 4 with two seams; band R-1 = the zipper band).  Its seam "transfers" are device-local copies by RCCL's own kernels: a
+rehearsal of the code path, not a scaling measurement, and the line says so.
 
 Exactly W untimed warm-up steps, then exactly K timed steps.  The auxiliary measurements the line also carries (fold-only
 launches by cache state, the same-shape copy ceiling, Float32 figures, config 2, config 5) run BEFORE the warm-up; the
@@ -45,7 +58,6 @@ SPECS = [("c", 0, 0, 1), ("u", 1, 0, -1), ("v", 0, 1, -1), ("zeta", 1, 1, 1)]   
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (datasheet)
 LIB = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "libtripolar_hip.so")
-KERNEL_SOURCE = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "csrc", "tpg_zipper_kernels.hpp")
 
 
 def zipper_algorithmic_bytes(nx, nz, hy, specs=SPECS, s=8):
@@ -160,6 +172,72 @@ class Watchdog:
         self.phase = "idle"
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_workers(args, argv, script=None):
+    """`python bench.py --gpus N` without a launcher: start the N workers ourselves.  This parent never imports torch and never
+    touches a GPU (no HIP call before or after the spawn; the children are fresh processes, no exec of an initialised one).
+    Rank 0's stdout is piped: its one JSON contract line is relayed to our stdout, anything else it prints goes to stderr; the
+    other ranks' stdout goes to stderr.  Exit status: 0 only if every child exits 0.  A child that dies takes the job down: the
+    survivors get 20 s (their watchdogs may still print a diagnostic), then SIGTERM, then SIGKILL -- by PID."""
+    import subprocess
+    n = args.gpus
+    csrc = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "csrc")
+    if not (os.path.exists(LIB) and os.path.exists(os.path.join(ROOT, "tools", "libtripolar_hip_test.so"))):
+        subprocess.check_call(["make", "-C", csrc, "-j4"], stdout=sys.stderr)          # fresh checkout: hipcc only, no GPU needed
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TPG_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on these hosts: RCCL's P2P setup needs it
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    relayed = []
+
+    def relay():
+        for ln in procs[0].stdout:
+            if ln.lstrip().startswith('{"metric"'):
+                relayed.append(ln)
+                sys.stdout.write(ln); sys.stdout.flush()
+            else:
+                sys.stderr.write(ln); sys.stderr.flush()
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    first_bad, t_bad = None, None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and first_bad is None:
+            first_bad, t_bad = bad[0], time.time()
+            print(f"[bench launcher] a worker exited with status {first_bad}; waiting 20 s for the others", file=sys.stderr, flush=True)
+        if first_bad is not None and time.time() - t_bad > 20:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(5)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    th.join(timeout=10)
+    codes = [p.returncode for p in procs]
+    rc = next((c for c in codes if c != 0), 0)
+    if rc == 0 and len(relayed) != 1:
+        print(f"[bench launcher] expected one contract line from rank 0, got {len(relayed)}", file=sys.stderr)
+        rc = 5
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,12 +245,28 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: strong = BASELINE config 4 (the 3600x1800x75 globe in N bands of 1800/N rows; default); weak = 1800 rows per rank")
+    ap.add_argument("--exchange", choices=("auto", "monolithic", "pipelined"), default="auto",
+                    help="N > 1: form of the RCCL seam exchange in the timed steps; auto = whichever the pre-pass measures faster (both are always reported)")
+    ap.add_argument("--loopback", action="store_true",
+                    help="1 GPU: run the N > 1 (RCCL) branch on a one-rank communicator whose peers are the rank itself")
+    ap.add_argument("--loopback-bands", type=int, default=8, help="--loopback: length R of the emulated latitude-band chain")
+    ap.add_argument("--loopback-band", type=int, default=3, help="--loopback: which band of the chain this GPU plays (R-1 = the zipper band)")
     ap.add_argument("--deadline", type=float, default=float(os.environ.get("TPG_BENCH_DEADLINE_S", "120")),
                     help="seconds allowed for communicator bring-up and for the first seam exchange (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fill-step", action="store_true", help="skip the config-5 (1/24 deg x 100 levels) fill_step measurement")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary measurements (cache states, copy ceiling, Float32, config 2, geometry)")
     args = ap.parse_args()
+
+    if args.loopback and args.gpus != 1:
+        raise SystemExit("--loopback is a one-GPU mode (--gpus 1)")
+    if args.loopback and not (0 <= args.loopback_band < args.loopback_bands and args.loopback_bands >= 2):
+        raise SystemExit("--loopback-band must lie in 0 .. --loopback-bands - 1 (bands >= 2)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one.  Checked BEFORE torch is imported or a device is touched.
+        if args.scaling == "strong" and NY % args.gpus:
+            raise SystemExit(f"--scaling strong needs {NY} % N == 0 (N = {args.gpus}); use N in 1,2,3,4,5,6,8,... or --scaling weak")
+        sys.exit(launch_workers(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -188,32 +282,43 @@ def main():
     from orthogonalsphericalshellgrids.jl_amd.distributed import PendingExchange
     from tools import testlib                                       # synthetic fill + copy probe only; every step call is the product library's
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))                  # processes = GPUs
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    strong = world > 1 and args.scaling == "strong"
-    if strong and NY % world:
+    # the latitude-band chain: one band per process -- or, --loopback, band r of an emulated chain of R on this one process
+    loopback = args.loopback
+    bands, band = (args.loopback_bands, args.loopback_band) if loopback else (world, rank)
+    chain = bands > 1
+    strong = chain and args.scaling == "strong"
+    if strong and NY % bands:
         # the remainder rule of Oceananigans' local_size for Ny % R != 0 is unpinned: config 4 divides evenly
-        raise SystemExit(f"--scaling strong needs {NY} % N == 0 (N = {world}); use N in 1,2,3,4,5,6,8,... or --scaling weak")
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    rehearse = os.environ.get("TPG_BENCH_REHEARSE") == "1"
+        raise SystemExit(f"--scaling strong needs {NY} % N == 0 (N = {bands}); use N in 1,2,3,4,5,6,8,... or --scaling weak")
+    assert torch.cuda.is_available(), f"bench.py needs a HIP device (rank {rank} of {world})"
+    rehearse = os.environ.get("TPG_BENCH_REHEARSE") == "1" and not loopback
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    peers = {"south": rank - 1 if rank > 0 else None, "north": rank + 1 if rank < world - 1 else None}
+    # RCCL peers (ranks of the communicator); -1 = no seam on that side.  Loop-back: both peers are this rank
+    if loopback:
+        south_peer, north_peer = (0 if band > 0 else -1), (0 if band < bands - 1 else -1)
+    else:
+        south_peer, north_peer = (rank - 1 if rank > 0 else -1), (rank + 1 if rank < world - 1 else -1)
+    north_is_zipper = band == bands - 1
+    peers = {"south": south_peer if south_peer >= 0 else None, "north": north_peer if north_peer >= 0 else None}
     dog = Watchdog(args.deadline, {"rank": rank, "world": world, "peers": peers, "device": local_rank})
+    if loopback:
+        dog.info.update(loopback={"bands": bands, "band": band})
     # Rehearsal mode for a 1-GPU box (never used by the driver): TPG_BENCH_REHEARSE=1 runs the N-rank
     # code path with every rank on cuda:0 and the seam messages staged through host memory over gloo
     # (RCCL refuses two ranks on one device).  Timings of such a run are meaningless.
     comm, comm_error = None, None
-    if world > 1:
+    if chain:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if loopback:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -234,19 +339,20 @@ def main():
                 comm.destroy(); comm = None
             dog.disarm()
             if comm is None:
+                if loopback:
+                    raise SystemExit(f"--loopback needs the C ABI's RCCL communicator: {comm_error}")
                 dog.info["transport"] = "torch.distributed batch_isend_irecv"
                 print(f"[bench rank {rank}] tpg_comm_init_rank unavailable ({comm_error}); seam exchange over torch.distributed", file=sys.stderr)
 
     lib, tlib = _lib.lib(), testlib.lib()
-    ny = NY // world if strong else NY                             # rows of this rank's band
-    gsize = (NX, NY, NZ) if (strong or world == 1) else (NX, NY * world, NZ)
-    if world > 1:
-        arch = osg.Distributed(osg.GPU(0 if rehearse else local_rank), osg.Partition(y=world), local_rank=rank, rccl_comm=comm)
+    ny = NY // bands if strong else NY                             # rows of this rank's band
+    gsize = (NX, NY, NZ) if (strong or not chain) else (NX, NY * bands, NZ)
+    if chain:
+        arch = osg.Distributed(osg.GPU(0 if rehearse else local_rank), osg.Partition(y=bands), local_rank=band, rccl_comm=comm)
         jstart, jend = osg.local_row_range(gsize[1], arch)
         assert jend - jstart + 1 == ny, (jstart, jend, ny)
     else:
         arch, jstart, jend = osg.GPU(local_rank), 1, NY
-    north_rank = rank == world - 1
 
     # ---- resident inputs / outputs -------------------------------------------------------------
     p = _lib.TpgParams(gsize[0], gsize[1], gsize[2], H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F64, jstart, jend, 0)
@@ -258,7 +364,7 @@ def main():
     fields = []
     for fid, _ in enumerate(SPECS):
         f = torch.empty(shape, dtype=torch.float64, device=dev)
-        testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0x5EED + fid + 16 * rank, 12345.0, NX, ny, NZ, H, H, H, _lib.TPG_F64, None))
+        testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0x5EED + fid + 16 * band, 12345.0, NX, ny, NZ, H, H, H, _lib.TPG_F64, None))
         fields.append(f)
     fptrs = _lib.ptr_table(fields)
     n = len(SPECS)
@@ -274,7 +380,7 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
     transport = None
-    if rehearse and world > 1:
+    if rehearse and chain:
         def transport(plan, send, recv, group):                     # host-staged stand-in for RCCL p2p
             hs = {k: v.cpu() for k, v in send.items()}
             hr = {k: torch.empty_like(v) for k, v in hs.items()}
@@ -284,12 +390,12 @@ def main():
 
     # seam message buffers: owned here for the C call (RCCL path), by the PendingExchange otherwise
     seam, seam_ptr = None, [None] * 4
-    if world > 1 and comm is not None:
+    if chain and comm is not None:
         nelem = int(lib.tpg_y_halo_buffer_elems(n, NX, NZ, H, H, H))
         seam = {k: torch.empty(nelem, dtype=torch.float64, device=dev) for k in ("ss", "sn", "rs", "rn")}
-        seam_ptr = [seam["ss"].data_ptr() if rank > 0 else None, seam["sn"].data_ptr() if not north_rank else None,
-                    seam["rs"].data_ptr() if rank > 0 else None, seam["rn"].data_ptr() if not north_rank else None]
-    pending = PendingExchange(band_fields, arch, transport) if (world > 1 and comm is None) else None
+        seam_ptr = [seam["ss"].data_ptr() if south_peer >= 0 else None, seam["sn"].data_ptr() if north_peer >= 0 else None,
+                    seam["rs"].data_ptr() if south_peer >= 0 else None, seam["rn"].data_ptr() if north_peer >= 0 else None]
+    pending = PendingExchange(band_fields, arch, transport) if (chain and comm is None) else None
 
     def hip_event():
         e = C.c_void_p()
@@ -301,29 +407,45 @@ def main():
         _lib.check(lib.tpg_event_elapsed_ms(e0, e1, C.byref(ms)))
         return ms.value
 
+    main_stream = torch.cuda.current_stream(dev)
+    side_stream = torch.cuda.Stream(dev) if chain else None         # the halo fill of a distributed step
+    comm_stream = torch.cuda.Stream(dev) if (chain and comm is not None) else None   # the RCCL groups of the pipelined exchange
+    comm_stream_ptr = C.c_void_p(comm_stream.cuda_stream) if comm_stream is not None else None
+    overlap = chain and os.environ.get("TPG_BENCH_OVERLAP", "1") != "0"
+    FORMS = ("monolithic", "pipelined") if comm is not None else ("monolithic",)
+    FIELDS_PER_STAGE = 1
+
     def local_fill(kev=None):
-        """fill_halo_regions! without the seams: zipper (north rank) -> periodic x; kev = the first kernel's own start/stop events"""
+        """fill_halo_regions! without the seams: zipper (north band) -> periodic x; kev = the first kernel's own start/stop events"""
         s_ = _lib.current_stream_ptr(dev)
         if kev is not None:
-            _lib.check(lib.tpg_fill_halo_regions_timed(fptrs, n, xl, yl, sg, *geom, 1 if north_rank else 0, _lib.TPG_F64, s_, kev[0], kev[1]))
+            _lib.check(lib.tpg_fill_halo_regions_timed(fptrs, n, xl, yl, sg, *geom, 1 if north_is_zipper else 0, _lib.TPG_F64, s_, kev[0], kev[1]))
         else:
-            _lib.check(lib.tpg_fill_halo_regions(fptrs, n, xl, yl, sg, *geom, 1 if north_rank else 0, _lib.TPG_F64, s_))
+            _lib.check(lib.tpg_fill_halo_regions(fptrs, n, xl, yl, sg, *geom, 1 if north_is_zipper else 0, _lib.TPG_F64, s_))
 
-    def exchange_only():
+    def exchange_only(form="monolithic"):
         s_ = _lib.current_stream_ptr(dev)
-        if comm is not None:
-            _lib.check(lib.tpg_halo_exchange_y(comm.handle, rank, world, fptrs, n, *seam_ptr, *geom, _lib.TPG_F64, s_))
-        else:
+        if comm is None:
             pending.begin().finish()
-
-    def distributed_fill():
-        """the whole fill_halo_regions! of a DistributedTripolarGrid: ONE C call on the RCCL path"""
-        if comm is not None:
-            _lib.check(lib.tpg_fill_halo_regions_distributed(comm.handle, rank, world, fptrs, n, xl, yl, sg, *seam_ptr, *geom, _lib.TPG_F64,
-                                                             _lib.current_stream_ptr(dev)))
+        elif form == "pipelined":
+            _lib.check(lib.tpg_halo_exchange_y_pipelined_peers(comm.handle, south_peer, north_peer, fptrs, n, *seam_ptr, *geom, _lib.TPG_F64,
+                                                               s_, comm_stream_ptr, FIELDS_PER_STAGE))
         else:
+            _lib.check(lib.tpg_halo_exchange_y_peers(comm.handle, south_peer, north_peer, fptrs, n, *seam_ptr, *geom, _lib.TPG_F64, s_))
+
+    def distributed_fill(form="monolithic"):
+        """the whole fill_halo_regions! of a DistributedTripolarGrid: ONE C call on the RCCL path, in either exchange form"""
+        s_ = _lib.current_stream_ptr(dev)
+        if comm is None:
             local_fill()
             exchange_only()
+        elif form == "pipelined":
+            _lib.check(lib.tpg_fill_halo_regions_distributed_pipelined_peers(comm.handle, south_peer, north_peer, 1 if north_is_zipper else 0,
+                                                                             fptrs, n, xl, yl, sg, *seam_ptr, *geom, _lib.TPG_F64,
+                                                                             s_, comm_stream_ptr, FIELDS_PER_STAGE))
+        else:
+            _lib.check(lib.tpg_fill_halo_regions_distributed_peers(comm.handle, south_peer, north_peer, 1 if north_is_zipper else 0,
+                                                                   fptrs, n, xl, yl, sg, *seam_ptr, *geom, _lib.TPG_F64, s_))
 
     def build():
         _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
@@ -333,9 +455,7 @@ def main():
         build()
         local_fill(kev)
 
-    main_stream = torch.cuda.current_stream(dev)
-    side_stream = torch.cuda.Stream(dev) if world > 1 else None
-    overlap = world > 1 and os.environ.get("TPG_BENCH_OVERLAP", "1") != "0"
+    used_form = ["monolithic"]
 
     def step_distributed(kev=None):
         """N > 1: the halo fill (zipper on the north rank -> periodic x -> seam exchange) on a side stream beside the grid
@@ -344,14 +464,14 @@ def main():
         if overlap:
             side_stream.wait_stream(main_stream)
             with torch.cuda.stream(side_stream):
-                distributed_fill()
+                distributed_fill(used_form[0])
             build()
             main_stream.wait_stream(side_stream)
         else:
-            distributed_fill()
+            distributed_fill(used_form[0])
             build()
 
-    step = step_distributed if world > 1 else step_serial
+    step = step_distributed if chain else step_serial
 
     def sync():
         torch.cuda.synchronize()
@@ -359,23 +479,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=None if rehearse else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     # ---- N > 1: first contact with the neighbours under a deadline ---------------------------------------------------------
-    if world > 1:
+    if chain:
         dog.info.update(geometry=list(geom), seam_message_MB=4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8 / 1e6)
         if os.environ.get("TPG_BENCH_TEST_STALL_RANK") == str(rank):      # tests/test_gpu_bench_contract.py: a rank that never posts its half
             time.sleep(3 * args.deadline)
             os._exit(4)
-        dog.arm("first seam exchange: enqueue (host inside ncclGroupEnd / batch_isend_irecv)")
-        distributed_fill()
-        dog.set_phase("first seam exchange: device (stream not drained: a peer never posted its half of the group?)")
-        torch.cuda.synchronize()
-        dog.set_phase("barrier after the first seam exchange")
-        dist.barrier()
-        dog.disarm()
+        for form in FORMS:
+            dog.arm(f"first seam exchange ({form}): enqueue (host inside ncclGroupEnd / batch_isend_irecv)")
+            with torch.cuda.stream(side_stream):
+                distributed_fill(form)
+            dog.set_phase(f"first seam exchange ({form}): device (stream not drained: a peer never posted its half of the group?)")
+            torch.cuda.synchronize()
+            if world > 1:
+                dog.set_phase(f"barrier after the first seam exchange ({form})")
+                dist.barrier()
+            dog.disarm()
         # the rest of the run (warm-up, timed and instrumented steps: a few seconds) stays under a generous second deadline, so that
         # an exchange that stalls LATER also ends with a diagnostic instead of the driver's kill
         dog.seconds = max(10 * args.deadline, 600.0)
-        dog.arm("warm-up / timed / instrumented steps (a seam exchange after the first one never completed)")
+        dog.arm("exchange pre-pass / warm-up / timed / instrumented steps (a seam exchange after the first one never completed)")
+
+    # ---- N > 1: which exchange form do the timed steps use?  Both are measured (fill + exchange alone on the side stream, no build
+    # beside it, 6 back-to-back fills after 2 untimed ones, one event pair around the lot, max over ranks); auto = the faster one ----
+    prepass = {}
+    if chain:
+        for form in FORMS:
+            sync()
+            with torch.cuda.stream(side_stream):
+                for _ in range(2):
+                    distributed_fill(form)
+                e0, e1 = ev(), ev()
+                e0.record()
+                for _ in range(6):
+                    distributed_fill(form)
+                e1.record()
+            torch.cuda.synchronize()
+            prepass[form] = reduce_max(e0.elapsed_time(e1) / 6)
+        if args.exchange != "auto":
+            if args.exchange not in FORMS:
+                raise SystemExit(f"--exchange {args.exchange}: not available on this transport ({dog.info.get('transport')})")
+            used_form[0] = args.exchange
+        else:
+            used_form[0] = min(FORMS, key=lambda f: prepass[f])     # the same on every rank: prepass holds max-over-ranks values
 
     # ---- auxiliary measurements (not steps) ----------------------------------------------------------------------------------
     # Order: the config-5 block first (it allocates and frees 162 GB), the config-3 auxiliary block last.  Neither order changes
@@ -384,10 +537,10 @@ def main():
     # (~25 ms; profiles/r03/cells_sequence_driver_args.txt).  `--steps 20 --warmup 5` times exactly that transient (0.64-0.66 ms per
     # step); the defaults (50 + 200 steps) time the steady state (0.56-0.58 ms).  DESIGN.md 6 quotes both.
     fill_step = None
-    if world == 1 and not args.no_fill_step:
+    if not chain and not args.no_fill_step:
         fill_step = fill_step_config5(torch, osg, _lib, tlib, dev)
     aux = {}
-    if world == 1 and not args.no_aux:
+    if not chain and not args.no_aux:
         aux = auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, sg, geom, p, out, out_ptrs, ws, hip_event, elapsed_ms)
 
     # ---- W warm-up steps, K timed steps ------------------------------------------------------------------------------------
@@ -397,8 +550,8 @@ def main():
     sync()
     # Timed region: K steps; the only instrumentation inside it is the fill kernel's own start/stop timestamps (they ride on its
     # dispatch packet; N = 1).  Stream-marker events between the phases cost ~10 us of queue bubbles each, so the per-phase
-    # breakdown is taken in a second, untimed pass of the same K steps.
-    kevs = [(hip_event(), hip_event()) for _ in range(args.steps)] if world == 1 else [None] * args.steps
+    # breakdown is taken in separate, untimed passes below.
+    kevs = [(hip_event(), hip_event()) for _ in range(args.steps)] if not chain else [None] * args.steps
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(kevs[k])
@@ -409,57 +562,67 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- untimed instrumented pass: phase brackets (and, N > 1, the north rank's fill-kernel duration) -----------------------
-    def reduce_max(x):
-        if world == 1:
-            return x
-        tt = torch.tensor([x], dtype=torch.float64, device=None if rehearse else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
-
-    marks = [[ev() for _ in range(6)] for _ in range(args.steps)]
-    kev2 = [(hip_event(), hip_event()) for _ in range(args.steps)] if (world > 1 and north_rank) else None
-    for k in range(args.steps):
-        m = marks[k]
-        if world == 1:
+    # ---- untimed instrumented passes ----------------------------------------------------------------------------------------
+    # N = 1: K steps with stream markers around the two phases (one stream anyway).
+    # N > 1: no marker ever sits on the build's stream between kernels.  (a) K builds back to back on the main stream, ONE event pair
+    # around the lot.  (b) per exchange form, K x [local fill, exchange] alone on the side stream with an event pair around each part
+    # (hipEventRecord on the side stream only).  The overlap of (a) and (b) inside a step is then read off the timed steps.
+    ex_ms, per_rank = {}, None
+    if not chain:
+        marks = [[ev() for _ in range(3)] for _ in range(args.steps)]
+        for k in range(args.steps):
+            m = marks[k]
             m[0].record(); build(); m[1].record(); local_fill(); m[2].record()
-        elif overlap:
-            side_stream.wait_stream(main_stream)
-            with torch.cuda.stream(side_stream):
-                m[3].record(); local_fill(kev2[k] if kev2 else None); m[4].record(); exchange_only(); m[5].record()
-            m[0].record(); build(); m[1].record()
-            main_stream.wait_stream(side_stream)
-        else:
-            m[3].record(); local_fill(kev2[k] if kev2 else None); m[4].record(); exchange_only(); m[5].record()
-            m[0].record(); build(); m[1].record()
-    sync()
-    avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)      # ms
-    t_build = avg(0, 1)
-    if world == 1:
-        t_fill_bracket, t_exchange, t_fillx = avg(1, 2), None, None
-        t_fill_kernel = sum(elapsed_ms(e0, e1) for e0, e1 in kevs) / len(kevs)      # the merged kernel's own duration, timed steps
+        sync()
+        avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)      # ms
+        t_build, t_fill_bracket, t_exchange, t_fillx = avg(0, 1), avg(1, 2), None, None
+        t_fill_kernel = sum(elapsed_ms(e0, e1) for e0, e1 in kevs) / len(kevs)          # the merged kernel's own duration, timed steps
         for e0, e1 in kevs:
             lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
     else:
-        t_fill_bracket, t_exchange, t_fillx = avg(3, 4), avg(4, 5), avg(3, 5)
-        t_fill_kernel = 0.0
-        if kev2:
-            t_fill_kernel = sum(elapsed_ms(e0, e1) for e0, e1 in kev2) / len(kev2)
-            for e0, e1 in kev2:
-                lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
-        # every rank's own phase times (instrumented pass) travel to rank 0 for the line: at N = 8 the interior ranks carry two
-        # seams, the end ranks one, and only the north rank folds
-        mine = {"rank": rank, "rows": [jstart, jend], "build_ms": t_build, "local_fill_ms": t_fill_bracket, "exchange_ms": t_exchange,
-                "fill_plus_exchange_ms": t_fillx, "seams": int(rank > 0) + int(not north_rank), "zipper": north_rank}
+        sync()
+        b0, b1 = ev(), ev()
+        b0.record()
+        for _ in range(args.steps):
+            build()
+        b1.record()
+        sync()
+        t_build = b0.elapsed_time(b1) / args.steps
+        t_fill_kernel, local_ms = 0.0, {}
+        for form in FORMS:
+            marks = [[ev() for _ in range(3)] for _ in range(args.steps)]
+            kev2 = [(hip_event(), hip_event()) for _ in range(args.steps)] if (north_is_zipper and form == "monolithic") else None
+            sync()
+            with torch.cuda.stream(side_stream):
+                for k in range(args.steps):
+                    m = marks[k]
+                    m[0].record(); local_fill(kev2[k] if kev2 else None); m[1].record(); exchange_only(form); m[2].record()
+            sync()
+            avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)
+            local_ms[form], ex_ms[form] = avg(0, 1), avg(1, 2)
+            if kev2:
+                t_fill_kernel = sum(elapsed_ms(e0, e1) for e0, e1 in kev2) / len(kev2)
+                for e0, e1 in kev2:
+                    lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
+        uf = used_form[0]
+        t_fill_bracket, t_exchange, t_fillx = local_ms[uf], ex_ms[uf], local_ms[uf] + ex_ms[uf]
+        # every band's own phase times travel to rank 0 for the line: at N = 8 the interior ranks carry two seams, the end ranks one,
+        # and only the north rank folds
+        mine = {"rank": rank, "band": band, "rows": [jstart, jend], "build_ms": t_build, "local_fill_ms": t_fill_bracket,
+                "exchange_ms": t_exchange, "exchange_ms_by_form": dict(ex_ms), "fill_plus_exchange_ms": t_fillx,
+                "seams": int(south_peer >= 0) + int(north_peer >= 0), "zipper": north_is_zipper}
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
-        t_build_max, t_exchange, t_fillx = reduce_max(t_build), reduce_max(t_exchange), reduce_max(t_fillx)
-        t_fill_kernel = reduce_max(t_fill_kernel)                                    # only the north rank has one
-        t_build = t_build_max
+        if world > 1:
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
+        t_build, t_exchange, t_fillx = reduce_max(t_build), reduce_max(t_exchange), reduce_max(t_fillx)
+        ex_ms = {f: reduce_max(v) for f, v in ex_ms.items()}
+        t_fill_kernel = reduce_max(t_fill_kernel)                                    # only the zipper band has one
 
     # ---- N = 1: fold-only pass, K old-style steps (build -> tpg_zipper_fill [k_zipper_cols] -> tpg_periodic_x_fill) -------
     fold = None
-    if world == 1:
+    if not chain:
         fevs = [(hip_event(), hip_event()) for _ in range(args.steps)]
         for k in range(args.steps):
             build()
@@ -472,56 +635,65 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        cells = gsize[0] * gsize[1]
+        # cells of one step: the whole globe (all bands) -- in loop-back only this band's share of it exists
+        cells = gsize[0] * gsize[1] if not loopback else NX * ny
         zbytes = sum(zipper_algorithmic_bytes(NX, NZ, H).values())
         pbytes = periodic_algorithmic_bytes(ny, NZ, H, n)
-        fill_bytes = zbytes + pbytes                                # north rank / N = 1
+        fill_bytes = (zbytes if (north_is_zipper or not loopback) else 0) + pbytes      # the zipper band / N = 1
         band_cells = (ny + 2 * H) * (NX + 2 * H)
+        jm_lo, jm_hi = max(1, jstart - H), min(gsize[1], jend + H)
+        evaluated_cells = NX * (jm_hi - jm_lo + 1)                  # cells the cell kernel computes (the band + its seam halo rows)
         line = {
             "metric": "grid-cells/s metric precompute + zipper halo-fill GB/s, 1/10°×75z",
             "value": cells / (elapsed / args.steps), "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak" if (world == 1 or not strong) else "strong",
+            "higher_is_better": True, "scaling": "weak" if (not chain or not strong) else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("TripolarGrid 1/10deg metric precompute (3600x1800, Float64, halo 4) + fill_halo_regions! of 4 fields "
-                                    "c/u/v/zeta (3600x1800x75): zipper + periodic-x in one merged launch" if world == 1 else
-                                    f"BASELINE config 4: the 1/10deg globe (3600x1800x75, Float64, halo 4) as {world} latitude bands of {ny} rows: per-band "
-                                    "metric precompute + fill_halo_regions! of c/u/v/zeta (zipper on the north rank, periodic-x, RCCL y-seam exchange)"
-                                    if strong else
-                                    f"weak scaling (not a BASELINE config): {world} bands of 1800 rows of a 3600x{NY * world}x75 globe: per-band metric "
-                                    "precompute + fill_halo_regions! of c/u/v/zeta (zipper on the north rank, periodic-x, RCCL y-seam exchange)"),
+                                    "c/u/v/zeta (3600x1800x75): zipper + periodic-x in one merged launch" if not chain else
+                                    (f"LOOP-BACK REHEARSAL on one GPU (not a scaling measurement): band {band} of {bands} of " if loopback else "")
+                                    + (f"BASELINE config 4: the 1/10deg globe (3600x1800x75, Float64, halo 4) as {bands} latitude bands of {ny} rows: per-band "
+                                       "metric precompute + fill_halo_regions! of c/u/v/zeta (zipper on the north rank, periodic-x, RCCL y-seam exchange)"
+                                       if strong else
+                                       f"weak scaling (not a BASELINE config): {bands} bands of 1800 rows of a 3600x{NY * bands}x75 globe: per-band metric "
+                                       "precompute + fill_halo_regions! of c/u/v/zeta (zipper on the north rank, periodic-x, RCCL y-seam exchange)")),
                        "global_size": list(gsize), "local_size": [NX, ny, NZ], "rows_per_rank": ny, "halo": [H, H, H],
-                       "fields": [s[0] for s in SPECS], "parallelism": f"latitude-bands x{world}"},
+                       "fields": [s[0] for s in SPECS], "parallelism": f"latitude-bands x{bands}" + (" (loop-back: one band on one GPU)" if loopback else "")},
             "precompute_cells_per_s": cells / (t_build * 1e-3),            # N > 1: all bands / the slowest rank's build
             "precompute_ms": t_build, "fill_ms": t_fill_kernel, "fill_bracket_ms": t_fill_bracket,
             "fill_GBps": fill_bytes / (t_fill_kernel * 1e-3) / 1e9 if t_fill_kernel else None,
         }
-        if world > 1:
+        if chain:
             seam_bytes = 4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8
             hidden = max(0.0, min(1.0, (t_build + t_fillx - ms_per_step) / max(1e-9, min(t_build, t_fillx))))
+            transport_name = ("gloo, host-staged (rehearsal: timings meaningless)" if rehearse
+                              else ("tpg_fill_halo_regions_distributed(_pipelined)_peers -> librccl ncclSend/ncclRecv groups, packed messages"
+                                    if comm is not None else "torch.distributed batch_isend_irecv (nccl = RCCL), packed messages [fallback]"))
             line.update({
                 "overlap": "halo fill (local fill + seam exchange) on a side stream, concurrent with the grid build" if overlap else None,
-                "exchange_ms": t_exchange,                          # pack + send/recv + unpack, slowest rank
+                "exchange_ms": t_exchange,                          # the form the timed steps used; pack + send/recv + unpack, slowest rank
+                "exchange_form": used_form[0], "exchange_form_choice": args.exchange,
+                "exchange_ms_monolithic": ex_ms.get("monolithic"), "exchange_ms_pipelined": ex_ms.get("pipelined"),
+                "exchange_fields_per_stage": FIELDS_PER_STAGE if "pipelined" in FORMS else None,
+                "exchange_prepass_fill_ms": prepass,                # whole fill (local + exchange), back to back, per form: what `auto` chose on
+                "link_floor_ms": seam_bytes / 153.6e9 * 1e3,        # one seam direction over one xGMI link at its ~153.6 GB/s spec figure
                 "fill_plus_exchange_ms": t_fillx, "exchange_over_build": t_exchange / t_build,
                 "overlap_hidden_frac": hidden if overlap else 0.0,  # share of the shorter of (build, fill + exchange) that the step hides
-                "exchange_transport": ("gloo, host-staged (rehearsal: timings meaningless)" if rehearse
-                                       else ("tpg_fill_halo_regions_distributed -> tpg_halo_exchange_y: librccl ncclSend/ncclRecv group, packed messages"
-                                             if comm is not None else "torch.distributed batch_isend_irecv (nccl = RCCL), packed messages [fallback]")),
+                "exchange_transport": transport_name + (" [loop-back: both peers are this rank, the transfers are device-local]" if loopback else ""),
                 "per_rank": per_rank,
+                "phase_timing": "build: one event pair around K back-to-back builds (main stream); local fill / exchange: hipEventRecord pairs on the "
+                                "side stream in a pass without the build; no marker sits on the build's stream inside a step",
                 "seam_message_bytes_per_direction": seam_bytes,
                 "seam_GBps_per_direction": seam_bytes / (t_exchange * 1e-3) / 1e9,
-                "note": "no multi-GPU curve exists until the driver runs one: this line is what each N prints"})
+                "note": ("loop-back rehearsal of the RCCL branch on one GPU: every code path of an N-rank run executes, no link is involved"
+                         if loopback else "no multi-GPU curve exists until the driver runs one: this line is what each N prints")})
+            if loopback:
+                line["loopback"] = {"bands": bands, "band": band, "south_peer": south_peer, "north_peer": north_peer, "zipper": north_is_zipper}
         line.update(aux)
         if fill_step is not None:
             line["fill_step"] = fill_step
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):                                   # PMC traffic is only valid for the build it was measured on
-            with open(tpath) as f:
-                tj = json.load(f)
-            if os.path.exists(KERNEL_SOURCE) and tj.get("kernel_source_sha16") == hashlib.sha256(open(KERNEL_SOURCE, "rb").read()).hexdigest()[:16]:
-                traffic = {k: v.get("hbm_bytes_per_launch") for k, v in tj.get("kernels", {}).items()}
-        if world == 1:
+        traffic = load_traffic()
+        if not chain:
             tm = traffic.get("k_fill_merged")
             line["roofline"] = {
                 "kernel": "k_fill_merged<double,2,4> (tpg_fill_halo_regions: 4 fields x 83 levels, zipper fold + periodic x, one launch)", "bound": "hbm",
@@ -549,25 +721,59 @@ def main():
                 "frac": fill_bytes / (t_fill_kernel * 1e-3) / 1e9 / HBM_PEAK_GBPS if t_fill_kernel else None, "traffic": None,
                 "algorithmic_bytes_per_launch": fill_bytes, "launch_ms": t_fill_kernel,
                 "measured": "the kernel's own start/stop events, instrumented pass after the timed steps"}
-        flops = 2285.0 * NX * ny                                                # FP64 add/mul/fma (fma = 2) per cell, PMC-counted on the round-3 kernel (profiles/r03/cells_trims.txt)
+        # the precompute: FP64 VALU issue is what bounds it (VALU busy 91 %), so THAT is `bound` / `frac`; its store stream is secondary.
+        # flops are per cell the kernel evaluates (band rows + the seam halo rows it computes), bytes per padded cell it stores
+        flops = 2285.0 * evaluated_cells                            # FP64 add/mul/fma (fma = 2) per cell, PMC-counted on the round-3 kernel (profiles/r03/cells_trims.txt)
+        tflops = flops / (t_build * 1e-3) / 1e12
         line["roofline_precompute"] = {
-            "kernel": "tpg_build_grid (k_tables + k_cells_tile + k_halos)" + (", slowest rank" if world > 1 else ""), "bound": "hbm",
-            "achieved": 160.0 * band_cells / (t_build * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("k_cells_tile"),
-            "algorithmic_bytes_per_launch": 160 * band_cells,
-            "fp64_tflops": flops / (t_build * 1e-3) / 1e12, "fp64_peak_tflops": FP64_VALU_PEAK_TFLOPS,
-            "fp64_frac": flops / (t_build * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-            "note": "FP64-issue bound in practice (VALU busy 91 %%): ~%.1f TFLOP/s of the %.1f TFLOP/s vector FP64 peak at 2.29 kflop/cell (PMC count)"
-                    % (flops / (t_build * 1e-3) / 1e12, FP64_VALU_PEAK_TFLOPS)}
-        if world == 1 and not args.no_cpu_baseline:
+            "kernel": "tpg_build_grid (k_tables + k_cells_tile + k_halos)" + (", slowest rank" if world > 1 else ""), "bound": "fp64_valu",
+            "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+            "flop_per_cell": 2285.0, "evaluated_cells": evaluated_cells, "stored_cells": band_cells,
+            "hbm_GBps": 160.0 * band_cells / (t_build * 1e-3) / 1e9, "hbm_frac": 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_launch": 160 * band_cells, "traffic": traffic.get("k_cells_tile"),
+            "note": "FP64-issue bound (VALU busy 91 %%): %.1f of the %.1f TFLOP/s vector FP64 peak at 2.29 kflop/cell (PMC count); the 160 B/cell store "
+                    "stream is %.0f %%%% of HBM peak" % (tflops, FP64_VALU_PEAK_TFLOPS, 100 * 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS)}
+        if not chain and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))          # ASCII-escaped: safe under any stdout encoding
-    if world > 1:
-        dist.barrier()
+    if chain:
+        if world > 1:
+            dist.barrier()
         dog.disarm()
         if comm is not None:
             comm.destroy()
         dist.destroy_process_group()
+
+
+def load_traffic():
+    """PMC traffic per kernel (profiles/traffic.json), valid only for the build it was measured on: every kernel entry carries the
+    file its kernel lives in and that file's hash at measurement time; an entry whose source has changed since is dropped."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return {}
+    with open(tpath) as f:
+        tj = json.load(f)
+    out, hashes = {}, {}
+    for k, v in tj.get("kernels", {}).items():
+        srcs = tuple(v.get("sources") or ())
+        if not srcs:
+            continue
+        if srcs not in hashes:
+            hashes[srcs] = sources_sha16(srcs)
+        if hashes[srcs] is not None and hashes[srcs] == v.get("sources_sha16"):
+            out[k] = v.get("hbm_bytes_per_launch")
+    return out
+
+
+def sources_sha16(srcs):
+    """one hash over the files (repo-relative) a kernel is compiled from; None if one is missing"""
+    h = hashlib.sha256()
+    for rel in srcs:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            return None
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, sg, geom, p, out, out_ptrs, ws, hip_event, elapsed_ms):

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TPG_VERSION 300 /* 0.3.0 */
+#define TPG_VERSION 400 /* 0.4.0 */
 
 enum tpg_status {
     TPG_OK = 0,
@@ -120,7 +120,9 @@ int tpg_zipper_fill(void *const fields[], int nfields,
                     int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
                     int kstart, int kcount, int ft, void *stream);
 
-/* Same call, with the kernel's own start / stop device timestamps recorded into two HIP events
+/* ---- profiling API (NO reference counterpart: measurement only, never needed by a host of the reference) ----
+ * tpg_zipper_fill_timed / tpg_fill_halo_regions_timed / tpg_event_create / tpg_event_destroy / tpg_event_elapsed_ms.
+ * Same call, with the kernel's own start / stop device timestamps recorded into two HIP events
  * (hipExtLaunchKernelGGL): what bench.py uses for roofline.achieved, so that the live number is the
  * kernel duration rocprofv3 reports, free of stream-marker and launch-boundary overhead.
  * nfields <= TPG_MAX_FIELDS (one kernel).  Events: tpg_event_create / hipEventCreate.  tpg_fill_halo_regions_timed (below)
@@ -152,6 +154,7 @@ int tpg_fill_halo_regions(void *const fields[], int nfields,
                           const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                           int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
                           int north_is_zipper, int ft, void *stream);
+/* profiling API, see tpg_zipper_fill_timed above */
 int tpg_fill_halo_regions_timed(void *const fields[], int nfields,
                                 const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                                 int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,
@@ -207,6 +210,27 @@ int tpg_halo_exchange_y_peers(void *comm, int south_peer, int north_peer, void *
                               void *send_south, void *send_north, void *recv_south, void *recv_north,
                               int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
 
+/* The packed exchange as a PIPELINE over stages of `fields_per_stage` fields (0 = 1; the message layout is
+ * [field][level][Hy][Nx+2Hx], so a stage is one contiguous slice of each message buffer):
+ *     stream       pack(0) pack(1) .. pack(S-1)            unpack(0)          unpack(1)  ..  unpack(S-1)
+ *     comm_stream          group(0)           group(1)  ..            group(S-1)
+ * group(s) = one ncclGroupStart/End with the sends / receives of stage s.  The link starts after ONE stage is packed, the
+ * other pack kernels run beside the first transfer and every unpack but the last beside the next transfer -- what the
+ * reference's per-field fill_halo_regions! gets from MPI Isend/Irecv progressing behind the next field's pack
+ * (src/distributed_tripolar_grid.jl:171,195 [Oceananigans' transport, recalled]).  Delivers exactly what the monolithic
+ * form delivers (same pack / unpack kernels on slices).  On return `stream` is ordered after every transfer and unpack, and
+ * comm_stream holds no work `stream` does not wait for.  comm_stream: a second hipStream_t of the caller on the same device
+ * (NULL or == stream: the same stages on one stream, no overlap).  All four message buffers are required for every side
+ * with a peer (no pack-free form).  The ordering events are created and destroyed inside the call. */
+int tpg_halo_exchange_y_pipelined(void *comm, int rank, int nranks, void *const fields[], int nfields,
+                                  void *send_south, void *send_north, void *recv_south, void *recv_north,
+                                  int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
+                                  void *stream, void *comm_stream, int fields_per_stage);
+int tpg_halo_exchange_y_pipelined_peers(void *comm, int south_peer, int north_peer, void *const fields[], int nfields,
+                                        void *send_south, void *send_north, void *recv_south, void *recv_north,
+                                        int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
+                                        void *stream, void *comm_stream, int fields_per_stage);
+
 /* fill_halo_regions!(fields...) on a DistributedTripolarGrid, whole, in ONE call and in the reference's order
  * (src/distributed_tripolar_grid.jl:143-147,177-185: the zipper only on the last rank; src/distributed_tripolar_grid.jl:171,195: every
  * other south / north side is neighbour communication): zipper fold (rank nranks-1) -> periodic x (merged / fused launch where
@@ -222,6 +246,18 @@ int tpg_fill_halo_regions_distributed_peers(void *comm, int south_peer, int nort
                                             const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                                             void *send_south, void *send_north, void *recv_south, void *recv_north,
                                             int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void *stream);
+/* The same whole fill with the seam exchange in its pipelined form (tpg_halo_exchange_y_pipelined above). */
+int tpg_fill_halo_regions_distributed_pipelined(void *comm, int rank, int nranks, void *const fields[], int nfields,
+                                                const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                                                void *send_south, void *send_north, void *recv_south, void *recv_north,
+                                                int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
+                                                void *stream, void *comm_stream, int fields_per_stage);
+int tpg_fill_halo_regions_distributed_pipelined_peers(void *comm, int south_peer, int north_peer, int north_is_zipper,
+                                                      void *const fields[], int nfields,
+                                                      const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                                                      void *send_south, void *send_north, void *recv_south, void *recv_north,
+                                                      int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
+                                                      void *stream, void *comm_stream, int fields_per_stage);
 
 /* ---- geometry utilities over the grid arrays -------------------------------
  * tpg_nonorthogonality_angle: compute_nonorthogonality_angle! of test/test_tripolar_grid.jl:8-34 as launched at

@@ -78,6 +78,12 @@ SIGNATURES = {
     "tpg_comm_destroy": (_i, [_vp]),
     "tpg_halo_exchange_y": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, _vp, _vp, _vp, _vp] + _geom + [_i, _vp]),
     "tpg_halo_exchange_y_peers": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, _vp, _vp, _vp, _vp] + _geom + [_i, _vp]),
+    "tpg_halo_exchange_y_pipelined": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, _vp, _vp, _vp, _vp] + _geom + [_i, _vp, _vp, _i]),
+    "tpg_halo_exchange_y_pipelined_peers": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, _vp, _vp, _vp, _vp] + _geom + [_i, _vp, _vp, _i]),
+    "tpg_fill_halo_regions_distributed_pipelined": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8),
+                                                         C.POINTER(C.c_int32), _vp, _vp, _vp, _vp] + _geom + [_i, _vp, _vp, _i]),
+    "tpg_fill_halo_regions_distributed_pipelined_peers": (_i, [_vp, _i, _i, _i, C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8),
+                                                               C.POINTER(C.c_int32), _vp, _vp, _vp, _vp] + _geom + [_i, _vp, _vp, _i]),
     "tpg_fill_halo_regions_distributed": (_i, [_vp, _i, _i, C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_int32),
                                                _vp, _vp, _vp, _vp] + _geom + [_i, _vp]),
     "tpg_fill_halo_regions_distributed_peers": (_i, [_vp, _i, _i, _i, C.POINTER(_vp), _i, C.POINTER(C.c_int8), C.POINTER(C.c_int8),

@@ -6,9 +6,12 @@
 // halos, all levels incl. the z halos) in both directions.  The reference's transport is MPI Isend/Irecv of one
 // packed buffer per side [recalled]; here it is ONE ncclGroupStart/ncclGroupEnd of point-to-point
 // ncclSend/ncclRecv on the caller's stream: no host wait, no collective (a y-slab chain only talks to its two
-// neighbours).  The exchange refuses a stream that is being captured into a HIP graph (TPG_ERR_UNSUPPORTED): RCCL's group
-// launch does its own stream / event work and, on a peer's first use, allocations -- tools/rccl_capture_probe.py is the
-// phase-by-phase record of what happens otherwise.  Two message shapes:
+// neighbours).  The exchange refuses a stream that is being captured into a HIP graph (TPG_ERR_UNSUPPORTED).  That fence is a
+// PRECAUTION for multi-rank first use (the first group towards a peer sets up the connection: allocations, IPC handles, a
+// proxy thread), which no box available to the build could exercise; on a single-rank communicator capture was shown to work
+// (five configurations complete and replay bit-exact: tools/rccl_capture_probe.py, profiles/r03/capture_probe/*.log), and the
+// stall reported in round 2 never reproduced -- its cause is unknown, the fence is not presented as its fix.
+// Two message shapes:
 //   packed    : tpg_pack_y_halo -> one message per seam direction ([field][level][Hy][sx], 9.58 MB per field at
 //               1/10 deg x 75 levels) -> tpg_unpack_y_halo;
 //   pack-free : the Hy seam rows of one (field, level) are already one contiguous window of the parent array
@@ -119,38 +122,58 @@ int tpg_comm_destroy(void* comm)
     return nccl_status(r, r->CommDestroy(static_cast<ncclComm_t>(comm)), "ncclCommDestroy");
 }
 
-int tpg_halo_exchange_y_peers(void* comm, int south_peer, int north_peer, void* const fields[], int nfields,
-                              void* send_south, void* send_north, void* recv_south, void* recv_north,
-                              int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream)
+// one stream's capture status: TPG_OK if the exchange may be enqueued on it
+static int capture_fence(hipStream_t s)
 {
+    // capture fence: a precaution, not a known failure -- single-rank capture works (profiles/r03/capture_probe/), but a multi-rank
+    // group's first use of a peer does connection setup that nothing here could test inside a capture; a host
+    // that wants graphs captures the local part of the fill and issues the exchange eagerly between replays
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const hipError_t ce = hipStreamIsCapturing(s, &cs);
+    if (ce != hipSuccess) (void)hipGetLastError();               // e.g. the legacy stream while another stream captures in global mode
+    if ((ce != hipSuccess || cs != hipStreamCaptureStatusNone) && !tpg::config().exchange_in_capture) {
+        tpg::set_error("tpg_halo_exchange_y: the stream is being captured into a HIP graph; the RCCL seam exchange is not offered inside a "
+                       "capture (untested with more than one rank: capture the local fill, issue the exchange eagerly)");
+        return TPG_ERR_UNSUPPORTED;
+    }
+    return TPG_OK;
+}
+
+// argument checks shared by the monolithic and the pipelined exchange; *nothing_to_do = 1 for Hy = 0 or a chain without seams
+static int exchange_checks(void* comm, int south_peer, int north_peer, void* const fields[], int nfields,
+                           void* send_south, void* send_north, void* recv_south, void* recv_north,
+                           int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, bool need_packed, int* nothing_to_do)
+{
+    *nothing_to_do = 0;
     int rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft);
     if (rc) return rc;
     if (!comm) { tpg::set_error("null communicator"); return TPG_ERR_INVALID_ARGUMENT; }
     if (!fields || nfields < 1) { tpg::set_error("no fields"); return TPG_ERR_INVALID_ARGUMENT; }
     for (int f = 0; f < nfields; ++f) if (!fields[f]) { tpg::set_error("null field %d", f); return TPG_ERR_INVALID_ARGUMENT; }
     if (nfields > TPG_MAX_FIELDS) { tpg::set_error("at most %d fields per exchange", TPG_MAX_FIELDS); return TPG_ERR_UNSUPPORTED; }
-    if (Hy == 0 || (south_peer < 0 && north_peer < 0)) return TPG_OK;
+    if (Hy == 0 || (south_peer < 0 && north_peer < 0)) { *nothing_to_do = 1; return TPG_OK; }
     const bool packed = send_south || send_north || recv_south || recv_north;
-    if (packed && ((south_peer >= 0 && (!send_south || !recv_south)) || (north_peer >= 0 && (!send_north || !recv_north)))) {
+    if ((packed || need_packed) && ((south_peer >= 0 && (!send_south || !recv_south)) || (north_peer >= 0 && (!send_north || !recv_north)))) {
         tpg::set_error("packed exchange: a message buffer is missing for a side that has a peer");
         return TPG_ERR_INVALID_ARGUMENT;
     }
+    return TPG_OK;
+}
+
+int tpg_halo_exchange_y_peers(void* comm, int south_peer, int north_peer, void* const fields[], int nfields,
+                              void* send_south, void* send_north, void* recv_south, void* recv_north,
+                              int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft, void* stream)
+{
+    int nothing = 0;
+    int rc = exchange_checks(comm, south_peer, north_peer, fields, nfields, send_south, send_north, recv_south, recv_north,
+                             Nx, Ny, Nz, Hx, Hy, Hz, ft, false, &nothing);
+    if (rc || nothing) return rc;
+    const bool packed = send_south || send_north || recv_south || recv_north;
     const Rccl* r = rccl();
     if (!r) return TPG_ERR_RCCL;
     ncclComm_t c = static_cast<ncclComm_t>(comm);
     hipStream_t s = tpg::as_stream(stream);
-    {
-        // capture fence: an RCCL group enqueued into a stream capture stalls or invalidates the capture;
-        // a host that wants graphs captures the local part of the fill and issues the exchange eagerly between replays
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        const hipError_t ce = hipStreamIsCapturing(s, &cs);
-        if (ce != hipSuccess) (void)hipGetLastError();               // e.g. the legacy stream while another stream captures in global mode
-        if ((ce != hipSuccess || cs != hipStreamCaptureStatusNone) && !tpg::config().exchange_in_capture) {
-            tpg::set_error("tpg_halo_exchange_y: the stream is being captured into a HIP graph; the RCCL seam exchange is not capturable "
-                           "(capture the local fill, issue the exchange eagerly)");
-            return TPG_ERR_UNSUPPORTED;
-        }
-    }
+    if ((rc = capture_fence(s))) return rc;
     const ncclDataType_t dt = ft == TPG_F64 ? ncclFloat64 : ncclFloat32;
     const size_t esz = ft == TPG_F64 ? 8 : 4;
     const size_t sx = (size_t)Nx + 2 * Hx, sy = (size_t)Ny + 2 * Hy, nlev = (size_t)Nz + 2 * Hz;
@@ -192,6 +215,102 @@ int tpg_halo_exchange_y_peers(void* comm, int south_peer, int north_peer, void* 
         if (north_peer >= 0 && (rc = tpg_unpack_y_halo(fields, nfields, recv_north, 1, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream))) return rc;
     }
     return TPG_OK;
+}
+
+// The packed exchange as a PIPELINE of stages of `fields_per_stage` fields (the message layout is [field][level][Hy][sx], so a
+// stage is one contiguous slice of each message buffer):
+//     stream       pack(0) pack(1) ... pack(S-1)          unpack(0)         unpack(1)  ...  unpack(S-1)
+//     comm_stream          group(0)          group(1) ...            group(S-1)
+// group(s) = one ncclGroupStart/End holding the sends / receives of stage s; it waits (event) for pack(s) and unpack(s) waits
+// (event) for it, so the link starts after ONE stage has been packed instead of all of them, the remaining pack kernels run
+// beside the first transfer and every unpack but the last runs beside the next stage's transfer.  At 1/10 deg x 75 levels, 4
+// fields, 8 bands: 2 x 13 us of pack + 2 x 13 us of unpack against >= 250 us on the link, of which 3/4 can hide.  What is
+// delivered is bit-identical to the monolithic form (same pack / unpack kernels on slices).  When the function returns, `stream`
+// is ordered after every transfer and unpack (its last wait), and comm_stream holds no work that `stream` does not wait for: the
+// message buffers may be reused by the next call on the same pair of streams.  comm_stream = NULL (or = stream) runs the same
+// stages on the one stream (no overlap).  The events that order the two streams are created and destroyed inside the call
+// (timing disabled); the library keeps nothing.
+int tpg_halo_exchange_y_pipelined_peers(void* comm, int south_peer, int north_peer, void* const fields[], int nfields,
+                                        void* send_south, void* send_north, void* recv_south, void* recv_north,
+                                        int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
+                                        void* stream, void* comm_stream, int fields_per_stage)
+{
+    int nothing = 0;
+    int rc = exchange_checks(comm, south_peer, north_peer, fields, nfields, send_south, send_north, recv_south, recv_north,
+                             Nx, Ny, Nz, Hx, Hy, Hz, ft, true, &nothing);
+    if (rc || nothing) return rc;
+    if (fields_per_stage < 0) { tpg::set_error("fields_per_stage %d < 0", fields_per_stage); return TPG_ERR_INVALID_ARGUMENT; }
+    const int fps = fields_per_stage == 0 ? 1 : (fields_per_stage > nfields ? nfields : fields_per_stage);
+    const int nstages = (nfields + fps - 1) / fps;
+    const Rccl* r = rccl();
+    if (!r) return TPG_ERR_RCCL;
+    ncclComm_t c = static_cast<ncclComm_t>(comm);
+    hipStream_t s = tpg::as_stream(stream);
+    hipStream_t cs = comm_stream ? tpg::as_stream(comm_stream) : s;
+    const bool two = cs != s;
+    if ((rc = capture_fence(s))) return rc;
+    if (two && (rc = capture_fence(cs))) return rc;
+    const ncclDataType_t dt = ft == TPG_F64 ? ncclFloat64 : ncclFloat32;
+    const size_t esz = ft == TPG_F64 ? 8 : 4;
+    const size_t per_field = tpg_y_halo_buffer_elems(1, Nx, Nz, Hx, Hy, Hz);
+    auto slice = [&](void* base, int f0) -> void* { return base ? static_cast<char*>(base) + (size_t)f0 * per_field * esz : nullptr; };
+
+    hipEvent_t packed_ev[TPG_MAX_FIELDS], moved_ev[TPG_MAX_FIELDS];
+    int nev = 0;
+    auto destroy_events = [&]() { for (int k = 0; k < nev; ++k) { (void)hipEventDestroy(packed_ev[k]); (void)hipEventDestroy(moved_ev[k]); } nev = 0; };
+    if (two) {
+        for (int k = 0; k < nstages; ++k) {
+            hipError_t e1 = hipEventCreateWithFlags(&packed_ev[k], hipEventDisableTiming);
+            if (e1 != hipSuccess) { destroy_events(); return tpg::hip_status(e1, "hipEventCreateWithFlags"); }
+            hipError_t e2 = hipEventCreateWithFlags(&moved_ev[k], hipEventDisableTiming);
+            if (e2 != hipSuccess) { (void)hipEventDestroy(packed_ev[k]); destroy_events(); return tpg::hip_status(e2, "hipEventCreateWithFlags"); }
+            nev = k + 1;
+        }
+    }
+#define TPG_PIPE_CHECK(expr) do { if ((rc = (expr))) { destroy_events(); return rc; } } while (0)
+    // every pack first: they depend on nothing but the local fill that precedes the call on `stream`
+    for (int k = 0; k < nstages; ++k) {
+        const int f0 = k * fps, n = nfields - f0 < fps ? nfields - f0 : fps;
+        if (north_peer >= 0) TPG_PIPE_CHECK(tpg_pack_y_halo(fields + f0, n, slice(send_north, f0), 1, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream));
+        if (south_peer >= 0) TPG_PIPE_CHECK(tpg_pack_y_halo(fields + f0, n, slice(send_south, f0), 0, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream));
+        if (two) TPG_PIPE_CHECK(tpg::hip_status(hipEventRecord(packed_ev[k], s), "hipEventRecord"));
+    }
+    for (int k = 0; k < nstages; ++k) {
+        const int f0 = k * fps, n = nfields - f0 < fps ? nfields - f0 : fps;
+        const size_t msg = (size_t)n * per_field;
+        if (two) TPG_PIPE_CHECK(tpg::hip_status(hipStreamWaitEvent(cs, packed_ev[k], 0), "hipStreamWaitEvent"));
+        // same order inside every group as in the monolithic form (a rank whose two peers are one rank pairs "sent north" with
+        // "received from the south"); groups towards one peer are matched in issue order, the same on both ends
+        TPG_PIPE_CHECK(nccl_status(r, r->GroupStart(), "ncclGroupStart"));
+        ncclResult_t e = ncclSuccess;
+        if (north_peer >= 0 && e == ncclSuccess) e = r->Send(slice(send_north, f0), msg, dt, north_peer, c, cs);
+        if (south_peer >= 0 && e == ncclSuccess) e = r->Send(slice(send_south, f0), msg, dt, south_peer, c, cs);
+        if (south_peer >= 0 && e == ncclSuccess) e = r->Recv(slice(recv_south, f0), msg, dt, south_peer, c, cs);
+        if (north_peer >= 0 && e == ncclSuccess) e = r->Recv(slice(recv_north, f0), msg, dt, north_peer, c, cs);
+        ncclResult_t e2 = r->GroupEnd();
+        TPG_PIPE_CHECK(nccl_status(r, e, "ncclSend/ncclRecv"));
+        TPG_PIPE_CHECK(nccl_status(r, e2, "ncclGroupEnd"));
+        if (two) {
+            TPG_PIPE_CHECK(tpg::hip_status(hipEventRecord(moved_ev[k], cs), "hipEventRecord"));
+            TPG_PIPE_CHECK(tpg::hip_status(hipStreamWaitEvent(s, moved_ev[k], 0), "hipStreamWaitEvent"));
+        }
+        if (south_peer >= 0) TPG_PIPE_CHECK(tpg_unpack_y_halo(fields + f0, n, slice(recv_south, f0), 0, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream));
+        if (north_peer >= 0) TPG_PIPE_CHECK(tpg_unpack_y_halo(fields + f0, n, slice(recv_north, f0), 1, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream));
+    }
+#undef TPG_PIPE_CHECK
+    destroy_events();      // recorded and waited-for events release their resources when they complete
+    return TPG_OK;
+}
+
+int tpg_halo_exchange_y_pipelined(void* comm, int rank, int nranks, void* const fields[], int nfields,
+                                  void* send_south, void* send_north, void* recv_south, void* recv_north,
+                                  int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
+                                  void* stream, void* comm_stream, int fields_per_stage)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks) { tpg::set_error("rank %d outside 0:%d", rank, nranks - 1); return TPG_ERR_BAD_PARTITION; }
+    return tpg_halo_exchange_y_pipelined_peers(comm, rank > 0 ? rank - 1 : -1, rank < nranks - 1 ? rank + 1 : -1, fields, nfields,
+                                               send_south, send_north, recv_south, recv_north, Nx, Ny, Nz, Hx, Hy, Hz, ft,
+                                               stream, comm_stream, fields_per_stage);
 }
 
 int tpg_halo_exchange_y(void* comm, int rank, int nranks, void* const fields[], int nfields,
@@ -238,6 +357,42 @@ int tpg_fill_halo_regions_distributed(void* comm, int rank, int nranks, void* co
     return tpg_fill_halo_regions_distributed_peers(comm, rank > 0 ? rank - 1 : -1, rank < nranks - 1 ? rank + 1 : -1, rank == nranks - 1,
                                                    fields, nfields, xloc, yloc, sign, send_south, send_north, recv_south, recv_north,
                                                    Nx, Ny, Nz, Hx, Hy, Hz, ft, stream);
+}
+
+// The same whole fill with the seam exchange pipelined per stage of `fields_per_stage` fields on `comm_stream`
+// (tpg_halo_exchange_y_pipelined_peers); packed messages only.
+int tpg_fill_halo_regions_distributed_pipelined_peers(void* comm, int south_peer, int north_peer, int north_is_zipper,
+                                                      void* const fields[], int nfields,
+                                                      const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                                                      void* send_south, void* send_north, void* recv_south, void* recv_north,
+                                                      int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
+                                                      void* stream, void* comm_stream, int fields_per_stage)
+{
+    if (north_is_zipper && north_peer >= 0) {
+        tpg::set_error("the north side is either the zipper or a seam, not both (north_peer %d)", north_peer);
+        return TPG_ERR_INVALID_ARGUMENT;
+    }
+    if (nfields > TPG_MAX_FIELDS && (south_peer >= 0 || north_peer >= 0)) {
+        tpg::set_error("at most %d fields per distributed fill (one seam message per side)", TPG_MAX_FIELDS);
+        return TPG_ERR_UNSUPPORTED;
+    }
+    int rc = tpg_fill_halo_regions(fields, nfields, xloc, yloc, sign, Nx, Ny, Nz, Hx, Hy, Hz, north_is_zipper ? 1 : 0, ft, stream);
+    if (rc) return rc;
+    if (south_peer < 0 && north_peer < 0) return TPG_OK;
+    return tpg_halo_exchange_y_pipelined_peers(comm, south_peer, north_peer, fields, nfields, send_south, send_north, recv_south, recv_north,
+                                               Nx, Ny, Nz, Hx, Hy, Hz, ft, stream, comm_stream, fields_per_stage);
+}
+
+int tpg_fill_halo_regions_distributed_pipelined(void* comm, int rank, int nranks, void* const fields[], int nfields,
+                                                const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
+                                                void* send_south, void* send_north, void* recv_south, void* recv_north,
+                                                int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
+                                                void* stream, void* comm_stream, int fields_per_stage)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks) { tpg::set_error("rank %d outside 0:%d", rank, nranks - 1); return TPG_ERR_BAD_PARTITION; }
+    return tpg_fill_halo_regions_distributed_pipelined_peers(comm, rank > 0 ? rank - 1 : -1, rank < nranks - 1 ? rank + 1 : -1, rank == nranks - 1,
+                                                             fields, nfields, xloc, yloc, sign, send_south, send_north, recv_south, recv_north,
+                                                             Nx, Ny, Nz, Hx, Hy, Hz, ft, stream, comm_stream, fields_per_stage);
 }
 
 }  // extern "C"

@@ -10,6 +10,8 @@ Three transports, all bit-identical in what they deliver:
   * RcclComm (the production path): the C ABI's tpg_fill_halo_regions_distributed -- the WHOLE fill of a band in one call: zipper
     (last rank) -> periodic x -> tpg_halo_exchange_y = pack -> ONE ncclGroupStart/End of ncclSend/ncclRecv on the caller's stream ->
     unpack (or pack-free: the per-level contiguous seam windows sent from / received into the fields directly).  No host wait.
+    `fields_per_stage = k` selects the PIPELINED form (tpg_fill_halo_regions_distributed_pipelined): the same messages in stages of k
+    fields, the RCCL group of stage s on a second stream beside pack(s+1..) and unpack(s-1); identical results.
     HaloFillPlan issues that call when the architecture carries an RcclComm.  The communicator is librccl's own
     (tpg_comm_init_rank); torch.distributed only ferries the 128-byte unique id, after every rank has reported that it can bind librccl.
   * torch_distributed_transport: `batch_isend_irecv` of the packed messages (backend "nccl" = RCCL, or "gloo" with
@@ -192,12 +194,19 @@ class PendingExchange:
     tpg_halo_exchange_y per batch (pack -> RCCL send/recv group -> unpack on the current stream, no host wait);
     begin() then does nothing and finish() runs it."""
 
-    def __init__(self, fields, arch, transport=None, pack_free=False):
+    def __init__(self, fields, arch, transport=None, pack_free=False, fields_per_stage=0):
         self.plan = exchange_plan(arch.local_rank, arch.ranks[1])
         self.fields, self.arch = list(fields), arch
         self.comm = getattr(arch, "rccl_comm", None) if transport is None else None
         self.transport = transport if transport is not None else torch_distributed_transport
         self.pack_free = pack_free and self.comm is not None
+        # fields_per_stage > 0: the PIPELINED form (tpg_halo_exchange_y_pipelined: stages of that many fields, the RCCL groups on a
+        # second stream beside the pack / unpack kernels of the neighbouring stages).  Other transports run the same stages one after
+        # the other -- same slices, same kernels, same result; only the RCCL path overlaps them.
+        if fields_per_stage < 0 or (fields_per_stage and pack_free):
+            raise ValueError("fields_per_stage must be >= 0 and excludes pack_free (the pipelined exchange is a packed one)")
+        self.fields_per_stage = int(fields_per_stage)
+        self._comm_stream = None
         self._handles = None
         self.batches = []                     # (fields, pointer table, SeamBuffers or None)
         if not self.plan:
@@ -218,9 +227,31 @@ class PendingExchange:
             stream = _lib.current_stream_ptr(self.device)
             for batch, ptrs, bufs in self.batches:
                 p = (lambda w, side: None) if bufs is None else bufs.ptr
-                _lib.check(lib.tpg_halo_exchange_y(self.comm.handle, self.arch.local_rank, self.arch.ranks[1], ptrs, len(batch),
-                                                   p("send", SOUTH), p("send", NORTH), p("recv", SOUTH), p("recv", NORTH),
-                                                   *self.geom, self.ft, stream))
+                if self.fields_per_stage:
+                    _lib.check(lib.tpg_halo_exchange_y_pipelined(self.comm.handle, self.arch.local_rank, self.arch.ranks[1], ptrs, len(batch),
+                                                                 p("send", SOUTH), p("send", NORTH), p("recv", SOUTH), p("recv", NORTH),
+                                                                 *self.geom, self.ft, stream, self.comm_stream_ptr(), self.fields_per_stage))
+                else:
+                    _lib.check(lib.tpg_halo_exchange_y(self.comm.handle, self.arch.local_rank, self.arch.ranks[1], ptrs, len(batch),
+                                                       p("send", SOUTH), p("send", NORTH), p("recv", SOUTH), p("recv", NORTH),
+                                                       *self.geom, self.ft, stream))
+
+    def comm_stream_ptr(self):
+        """the second stream of the pipelined exchange (this object's own, created at first use)"""
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(self.device)
+        return C.c_void_p(self._comm_stream.cuda_stream)
+
+    def _stages(self, nbatch):
+        """(first field, count) of every stage of a batch of `nbatch` fields; one stage = the whole batch when not pipelined"""
+        fps = min(self.fields_per_stage, nbatch) if self.fields_per_stage else nbatch
+        return [(f0, min(fps, nbatch - f0)) for f0 in range(0, nbatch, fps)]
+
+    def _slice(self, batch, ptrs, buf, f0, n):
+        """pointer table and message slice of fields f0 .. f0+n-1 of a batch (message layout [field][level][Hy][sx])"""
+        if f0 == 0 and n == len(batch):
+            return ptrs, buf.data_ptr()
+        return _lib.ptr_table([f.data for f in batch[f0:f0 + n]]), buf[f0:f0 + n].data_ptr()
 
     def begin(self):
         if not self.plan or self.comm is not None:
@@ -233,8 +264,10 @@ class PendingExchange:
         with torch.cuda.device(self.device):
             stream = _lib.current_stream_ptr(self.device)
             for batch, ptrs, bufs in self.batches:
-                for m in self.plan:
-                    _lib.check(lib.tpg_pack_y_halo(ptrs, len(batch), bufs.send[m.side].data_ptr(), m.side, *self.geom, self.ft, stream))
+                for f0, n in self._stages(len(batch)):               # pipelined: one pack launch per stage and side, on that stage's slice
+                    for m in self.plan:
+                        pt, dst = self._slice(batch, ptrs, bufs.send[m.side], f0, n)
+                        _lib.check(lib.tpg_pack_y_halo(pt, n, dst, m.side, *self.geom, self.ft, stream))
                 self._handles.append(self.transport.post(self.plan, bufs.send, bufs.recv, group) if hasattr(self.transport, "post") else None)
         return self
 
@@ -254,12 +287,14 @@ class PendingExchange:
                     self.transport.wait(handle)
                 else:
                     self.transport(self.plan, bufs.send, bufs.recv, group)
-                for m in self.plan:
-                    _lib.check(lib.tpg_unpack_y_halo(ptrs, len(batch), bufs.recv[m.side].data_ptr(), m.side, *self.geom, self.ft, stream))
+                for f0, n in self._stages(len(batch)):
+                    for m in self.plan:
+                        pt, src = self._slice(batch, ptrs, bufs.recv[m.side], f0, n)
+                        _lib.check(lib.tpg_unpack_y_halo(pt, n, src, m.side, *self.geom, self.ft, stream))
         self._handles = None
 
 
-def exchange_y_halos(fields, arch, transport: Optional[Callable] = None, pack_free: bool = False):
+def exchange_y_halos(fields, arch, transport: Optional[Callable] = None, pack_free: bool = False, fields_per_stage: int = 0):
     """Fill the y-seam halo rows of `fields` (one geometry) from the neighbour ranks (one-off: allocates its message
     buffers; keep a PendingExchange / HaloFillPlan for repeated fills)."""
-    PendingExchange(fields, arch, transport, pack_free).begin().finish()
+    PendingExchange(fields, arch, transport, pack_free, fields_per_stage).begin().finish()

@@ -219,12 +219,16 @@ class HaloFillPlan:
     The plan holds the fields' tensors: it must be rebuilt if a field's `data` is replaced.
     """
 
-    def __init__(self, fields, *, exchange=None, pack_free=False):
+    def __init__(self, fields, *, exchange=None, pack_free=False, fields_per_stage=0):
         if isinstance(fields, Field):
             fields = [fields]
         self.fields = list(fields)
         self._exchange = exchange
         self._pack_free = pack_free
+        if fields_per_stage < 0 or (fields_per_stage and pack_free):
+            raise ValueError("fields_per_stage must be >= 0 and excludes pack_free (the pipelined seam exchange is a packed one)")
+        self._fields_per_stage = int(fields_per_stage)      # > 0: pipelined seam exchange in stages of that many fields (distributed grids)
+        self._comm_streams = {}                               # device -> the second stream of the pipelined RCCL exchange
         self._steps = []                      # (device, [(c function, argument tuple without the stream)], PendingExchange or None)
         self._keep = []                       # message buffers referenced by raw pointer from the argument tuples
         lib = _lib.lib()
@@ -253,9 +257,16 @@ class HaloFillPlan:
                     bufs = None if pack_free else SeamBuffers(message_shape(len(batch), f0), f0.data.dtype, f0.data.device, plan)
                     self._keep.append(bufs)
                     p = (lambda w, side: None) if bufs is None else bufs.ptr
-                    calls.append((lib.tpg_fill_halo_regions_distributed,
-                                  (comm.handle, arch.local_rank, arch.ranks[1], _lib.ptr_table([f.data for f in batch]), len(batch), xl, yl, sg,
-                                   p("send", SOUTH), p("send", NORTH), p("recv", SOUTH), p("recv", NORTH), *geom, ft)))
+                    args = (comm.handle, arch.local_rank, arch.ranks[1], _lib.ptr_table([f.data for f in batch]), len(batch), xl, yl, sg,
+                            p("send", SOUTH), p("send", NORTH), p("recv", SOUTH), p("recv", NORTH), *geom, ft)
+                    if self._fields_per_stage:
+                        dev = f0.data.device
+                        if dev not in self._comm_streams:
+                            self._comm_streams[dev] = torch.cuda.Stream(dev)
+                        calls.append((lib.tpg_fill_halo_regions_distributed_pipelined, args,
+                                      (C.c_void_p(self._comm_streams[dev].cuda_stream), self._fields_per_stage)))
+                    else:
+                        calls.append((lib.tpg_fill_halo_regions_distributed, args))
             else:
                 if zip_fs and len(zip_fs) == len(fs):
                     # the usual case: one entry point for zipper -> periodic x (a single fused launch for small
@@ -270,7 +281,7 @@ class HaloFillPlan:
                     calls.append((lib.tpg_periodic_x_fill, (_lib.ptr_table([f.data for f in fs]), len(fs), *geom, ft)))
                 if distributed:
                     from .distributed import PendingExchange
-                    pending = PendingExchange(fs, arch, exchange, pack_free)     # owns its message buffers; reused every fill
+                    pending = PendingExchange(fs, arch, exchange, pack_free, self._fields_per_stage)     # owns its message buffers; reused every fill
             self._steps.append((f0.data.device, calls, pending))
 
     @property
@@ -283,13 +294,13 @@ class HaloFillPlan:
         for device, calls, pending in self._steps:
             if torch.cuda.current_device() == device.index:     # the common case: no device switch to pay for
                 stream = _lib.current_stream_ptr(device)
-                for fn, args in calls:
-                    _lib.check(fn(*args, stream))
+                for fn, args, *after in calls:                 # after: arguments that follow the stream (pipelined exchange)
+                    _lib.check(fn(*args, stream, *(after[0] if after else ())))
             else:
                 with torch.cuda.device(device):
                     stream = _lib.current_stream_ptr(device)
-                    for fn, args in calls:
-                        _lib.check(fn(*args, stream))
+                    for fn, args, *after in calls:
+                        _lib.check(fn(*args, stream, *(after[0] if after else ())))
             if pending is not None:
                 pending.begin()
         return self
@@ -325,8 +336,8 @@ class HaloFillPlan:
         return g
 
 
-def halo_fill_plan(fields, *, exchange=None, pack_free=False):
-    return HaloFillPlan(fields, exchange=exchange, pack_free=pack_free)
+def halo_fill_plan(fields, *, exchange=None, pack_free=False, fields_per_stage=0):
+    return HaloFillPlan(fields, exchange=exchange, pack_free=pack_free, fields_per_stage=fields_per_stage)
 
 
 def fill_halo_regions(fields, *, exchange=None):

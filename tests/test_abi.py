@@ -35,11 +35,17 @@ def test_header_symbols_are_all_exported_and_bound(osg):
     assert sorted(osg._lib.SIGNATURES) == names
 
 
-def test_product_library_exports_exactly_the_reference_facing_abi(osg):
+PROFILING_API = ["tpg_event_create", "tpg_event_destroy", "tpg_event_elapsed_ms", "tpg_fill_halo_regions_timed", "tpg_zipper_fill_timed"]
+
+
+def test_product_library_exports_exactly_the_header(osg):
     """libtripolar_hip.so exports the symbols of include/tripolar_hip.h and NOTHING else: no test / bench hook, no C++ symbol,
-    no knob reload; the hooks live in tools/libtripolar_hip_test.so (include/tripolar_hip_test.h) = product symbols + 4"""
+    no knob reload; the hooks live in tools/libtripolar_hip_test.so (include/tripolar_hip_test.h) = product symbols + 4.
+    Of the header's symbols five are its "profiling API" (kernel-event timing, no reference counterpart) and say so."""
     product = exported_symbols(osg._lib.LIB_PATH)
     assert product == declared_symbols()
+    header = open(os.path.join(ROOT, "include", "tripolar_hip.h")).read()
+    assert "profiling API (NO reference counterpart" in header and all(n in product for n in PROFILING_API)
     assert not set(product) & set(TEST_ONLY)
     from tools import testlib
     assert declared_symbols("tripolar_hip_test.h") == TEST_ONLY
@@ -55,7 +61,7 @@ def test_product_library_exports_exactly_the_reference_facing_abi(osg):
 
 def test_version_and_status_strings(osg):
     lib = osg._lib.lib()
-    assert lib.tpg_version() == 300
+    assert lib.tpg_version() == 400
     assert b"even" in lib.tpg_status_string(-2)
     assert lib.tpg_status_string(0) == b"ok"
 
@@ -106,6 +112,15 @@ def test_distributed_fill_argument_errors_without_device_work(osg):
     # the north side is the zipper OR a seam
     assert lib.tpg_fill_halo_regions_distributed_peers(None, -1, 1, 1, fields, 1, xl, yl, sg, None, None, None, None, *geom, 1, None) == -1
     assert b"zipper or a seam" in lib.tpg_last_error()
+    # the pipelined forms validate the same way, and additionally refuse a missing message buffer / a negative stage size
+    assert lib.tpg_fill_halo_regions_distributed_pipelined(None, 2, 2, fields, 1, xl, yl, sg, None, None, None, None, *geom, 1, None, None, 1) == -3
+    assert lib.tpg_fill_halo_regions_distributed_pipelined_peers(None, -1, 1, 1, fields, 1, xl, yl, sg, None, None, None, None, *geom, 1,
+                                                                 None, None, 1) == -1
+    assert lib.tpg_halo_exchange_y_pipelined(1 << 20, 0, 2, fields, 1, None, None, None, None, *geom, 1, None, None, 1) == -1   # pack-free: not offered
+    assert b"message buffer" in lib.tpg_last_error()
+    assert lib.tpg_halo_exchange_y_pipelined(1 << 20, 0, 2, fields, 1, 1 << 20, 1 << 20, 1 << 20, 1 << 20, *geom, 1, None, None, -2) == -1
+    assert b"fields_per_stage" in lib.tpg_last_error()
+    assert lib.tpg_halo_exchange_y_pipelined(None, 0, 2, fields, 1, None, None, None, None, *geom, 1, None, None, 1) == -1          # null communicator
     # argument validation of the local fill comes first (odd Nx), before any communicator is looked at
     assert lib.tpg_fill_halo_regions_distributed(None, 0, 2, fields, 1, xl, yl, sg, None, None, None, None, 11, 10, 1, 4, 4, 4, 1, None) == -2
     assert lib.tpg_comm_available() in (0, -7)

@@ -4,6 +4,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -38,6 +39,9 @@ def test_bench_prints_one_contract_line(gpu):
     assert f["bound"] == "hbm" and "k_zipper_cols" in f["kernel"] and f["algorithmic_bytes_per_launch"] == zb
     assert abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-12 and 0.2 < f["frac"] < 1.0
     assert f["traffic"] is None or f["traffic"] >= 0.95 * zb
+    rp = d["roofline_precompute"]                    # FP64-issue bound: that is its `bound` / `frac`; the store stream is secondary
+    assert rp["bound"] == "fp64_valu" and rp["unit"] == "TFLOP/s" and rp["peak"] == 78.6 and abs(rp["frac"] - rp["achieved"] / rp["peak"]) < 1e-12
+    assert 0.05 < rp["frac"] < 1.0 and 0.05 < rp["hbm_frac"] < 1.0 and rp["evaluated_cells"] == 3600 * 1800 and rp["stored_cells"] == 3608 * 1808
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "cells/s" and c["value"] > 1e5 and "oracle" in c["sample"]
     assert d["value"] > 100 * c["value"]            # sanity: the HIP path is the thing measured, not the oracle
@@ -59,57 +63,102 @@ def test_bench_prints_one_contract_line(gpu):
                                and abs(fs["total_us"] - fs["fill3d_us"] - fs["substep_fills_us"]) < 1e-6 and fs["fields_GB"] > 160)
 
 
-def _two_rank_bench(extra):
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+def _two_rank_bench(extra, launcher="self"):
+    """two ranks on this one GPU (TPG_BENCH_REHEARSE=1: gloo, host-staged seams).  launcher "self": `python bench.py --gpus 2`, no
+    launcher on the command line -- bench.py starts its own workers (what the driver's N = 1 command form becomes at N > 1);
+    "torchrun": the documented `python -m torch.distributed.run ...` form."""
     env = dict(os.environ, TPG_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), p.stdout[-2000:]       # stdout is the one contract line, nothing else
     return json.loads(lines[0])
 
 
 def test_bench_two_ranks_rehearsal(gpu):
-    """The N > 1 code path of bench.py as a FRESH child process: two ranks on this one GPU, seam messages host-staged over gloo
-    (RCCL refuses two ranks on one device; the RCCL leg itself is tests/test_gpu_exchange.py).  Default = STRONG scaling =
-    BASELINE config 4's geometry (the 3600 x 1800 x 75 globe in N bands; N = 2 here: 900 rows each, the zipper on rank 1);
-    `--scaling weak` is the named alternative.  Timings of such a run mean nothing; the contract does."""
+    """The N > 1 code path of bench.py as FRESH child processes: `python bench.py --gpus 2` with NO launcher -- bench.py spawns its
+    two workers itself, before importing torch -- both on this one GPU, seam messages host-staged over gloo (RCCL refuses two ranks
+    on one device; the RCCL leg itself is test_bench_loopback_runs_the_rccl_branch and tests/test_gpu_exchange.py).  Default =
+    STRONG scaling = BASELINE config 4's geometry (the 3600 x 1800 x 75 globe in N bands; N = 2 here: 900 rows each, the zipper on
+    rank 1); `--scaling weak` is the named alternative, run here through torchrun (the other launch form).  Timings of such a run
+    mean nothing; the contract does."""
     d = _two_rank_bench([])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["config"]["global_size"] == [3600, 1800, 75] and d["config"]["local_size"] == [3600, 900, 75]
     assert d["config"]["rows_per_rank"] == 900 and d["config"]["parallelism"] == "latitude-bands x2" and "config 4" in d["config"]["workload"]
     assert isinstance(d["exchange_ms"], float) and d["exchange_ms"] > 0 and "gloo" in d["exchange_transport"]
+    assert d["exchange_form"] == "monolithic" and d["exchange_ms_monolithic"] == d["exchange_ms"] and d["exchange_ms_pipelined"] is None
+    assert abs(d["link_floor_ms"] - 4 * 3608 * 4 * 83 * 8 / 153.6e9 * 1e3) < 1e-9
     assert d["seam_GBps_per_direction"] > 0 and d["overlap"] is not None and 0.0 <= d["overlap_hidden_frac"] <= 1.0
     assert d["exchange_over_build"] > 0 and d["fill_plus_exchange_ms"] >= d["exchange_ms"]
     assert abs(d["value"] - 3600 * 1800 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]            # the globe is fixed: strong
     assert d["precompute_cells_per_s"] > 0 and d["roofline"]["launch_ms"] > 0
+    rp = d["roofline_precompute"]
+    assert rp["bound"] == "fp64_valu" and rp["unit"] == "TFLOP/s" and abs(rp["frac"] - rp["achieved"] / rp["peak"]) < 1e-12
+    assert rp["evaluated_cells"] == 3600 * 904 and rp["stored_cells"] == 3608 * 908                   # a 900-row band + one seam's halo rows
     pr = d["per_rank"]                                                # every rank's own phase times
     assert [r["rank"] for r in pr] == [0, 1] and pr[0]["rows"] == [1, 900] and pr[1]["rows"] == [901, 1800]
     assert [r["zipper"] for r in pr] == [False, True] and [r["seams"] for r in pr] == [1, 1] and all(r["build_ms"] > 0 for r in pr)
     assert "cpu_baseline" not in d and "fill_step" not in d           # rank 0 at N = 1 only
-    w = _two_rank_bench(["--scaling", "weak"])
+    w = _two_rank_bench(["--scaling", "weak"], launcher="torchrun")
     assert w["scaling"] == "weak" and w["config"]["global_size"] == [3600, 3600, 75] and w["config"]["local_size"] == [3600, 1800, 75]
     assert abs(w["value"] - 2 * 3600 * 1800 / (w["ms_per_step"] * 1e-3)) <= 1e-6 * w["value"]
+
+
+@pytest.mark.parametrize("band", [3, 7])
+def test_bench_loopback_runs_the_rccl_branch(gpu, band):
+    """`bench.py --loopback`: the `comm is not None` branch of bench.py on a one-GPU box -- RcclComm bring-up under the watchdog,
+    seam buffers, tpg_fill_halo_regions_distributed_peers AND its pipelined form (first contact, pre-pass, timed steps on the side
+    stream beside the build, instrumented passes), for band 3 of 8 (interior: two seams) and band 7 of 8 (zipper + south seam) of
+    BASELINE config 4.  Both peers are the rank itself: no link, no scaling claim -- the line must say so."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TPG_BENCH_REHEARSE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--loopback", "--loopback-band", str(band), "--steps", "6", "--warmup", "2"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["rows_per_rank"] == 225 and "LOOP-BACK" in d["config"]["workload"]
+    assert d["loopback"] == {"bands": 8, "band": band, "south_peer": 0, "north_peer": 0 if band < 7 else -1, "zipper": band == 7}
+    assert "librccl" in d["exchange_transport"] and "loop-back" in d["exchange_transport"] and "rehearsal" in d["note"]
+    assert d["exchange_ms_monolithic"] > 0 and d["exchange_ms_pipelined"] > 0 and d["exchange_form"] in ("monolithic", "pipelined")
+    assert d["exchange_ms"] == d["exchange_ms_" + d["exchange_form"]] and d["exchange_fields_per_stage"] == 1
+    assert set(d["exchange_prepass_fill_ms"]) == {"monolithic", "pipelined"}
+    assert abs(d["value"] - 3600 * 225 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]                # this band's cells only
+    pr = d["per_rank"]
+    assert len(pr) == 1 and pr[0]["band"] == band and pr[0]["seams"] == (2 if band < 7 else 1) and pr[0]["zipper"] == (band == 7)
+    assert pr[0]["rows"] == [225 * band + 1, 225 * band + 225] and set(pr[0]["exchange_ms_by_form"]) == {"monolithic", "pipelined"}
+    assert (d["roofline"]["launch_ms"] > 0) == (band == 7)                                               # only the zipper band launches the merged fold
+    assert d["roofline_precompute"]["evaluated_cells"] == 3600 * (233 if band < 7 else 229)
+    assert "cpu_baseline" not in d and "fill_step" not in d
 
 
 def test_bench_deadline_fires_with_a_diagnostic(gpu):
     """A stalled first exchange must end the job loudly: rank 1 of a two-rank rehearsal is told (TPG_BENCH_TEST_STALL_RANK) to sleep
     instead of entering its first fill, so rank 0 blocks in the gloo exchange; with a 10 s deadline rank 0 prints the one-line JSON
-    diagnostic (rank, peers, phase) on stderr and the job exits non-zero -- no JSON line on stdout."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    diagnostic (rank, peers, phase) on stderr and the job exits non-zero -- no JSON line on stdout.  Launched WITHOUT a launcher:
+    bench.py's own parent must pass the failure on (non-zero exit) and stop the sleeping worker."""
     env = dict(os.environ, TPG_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1", TPG_BENCH_TEST_STALL_RANK="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--deadline", "10"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--deadline", "10"]
+    t0 = time.time()
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert p.returncode != 0
+    assert p.returncode != 0 and time.time() - t0 < 200
     assert not [l for l in p.stdout.splitlines() if l.strip().startswith('{"metric"')]
     diag = [json.loads(l[l.index("{"):]) for l in p.stderr.splitlines() if "bench_deadline_expired" in l]
     assert diag, p.stderr[-3000:]

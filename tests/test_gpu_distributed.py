@@ -11,9 +11,10 @@ SENT = 12345.0
 SPECS = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]
 
 
+@pytest.mark.parametrize("stage", [0, 1, 3])      # 0: monolithic exchange; k: the pipelined form's stages of k fields (4 fields: 4 / 2 stages)
 @pytest.mark.parametrize("R", [2, 4])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype):
+def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype, stage):
     size, halo = (48, 40, 3), (4, 4, 2)
     (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
     tdt = torch.float64 if dtype == np.float64 else torch.float32
@@ -44,7 +45,7 @@ def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype):
 
     # phase 1 on every rank: zipper (north rank) + periodic x + pack + post; phase 2: delivery + the product's own unpack
     mailbox = osg.LoopbackMailbox()
-    plans = [osg.halo_fill_plan(fs, exchange=mailbox.endpoint(r)) for r, (arch, grid, fs) in enumerate(ranks)]
+    plans = [osg.halo_fill_plan(fs, exchange=mailbox.endpoint(r), fields_per_stage=stage) for r, (arch, grid, fs) in enumerate(ranks)]
     for plan in plans:
         plan.begin()
     for plan in plans:

@@ -25,11 +25,16 @@ def test_rccl_seam_exchange_single_rank_loopback(gpu):
     assert {c["packed"] for c in d["cases"]} == {True, False}
     assert [3600, 225, 75] in [c["size"] for c in d["cases"]]                       # BASELINE config 4's band geometry (ny = 225)
     # the whole band fill through ONE C call (tpg_fill_halo_regions_distributed_peers): a middle band and the zipper band
-    assert [c["band"] for c in d["distributed_fill"]] == ["middle", "north"] and all(c["bit_exact"] for c in d["distributed_fill"])
+    assert [(c["band"], c["pipelined"]) for c in d["distributed_fill"]] == [("middle", False), ("north", False), ("middle", True), ("north", True)]
+    assert all(c["bit_exact"] and c["rc"] == 0 for c in d["distributed_fill"])
+    # the pipelined packed exchange (stages of 1, 2, 3, all fields; one stream and two; two seams / south only / north only; called twice
+    # on the same buffers) delivers exactly the monolithic result, incl. config 4's 3600 x 225 x 75 band
+    assert d["pipelined"]["cases"] >= 40 and d["pipelined"]["all_bit_exact"], d["pipelined"]["failed"][:3]
+    assert set(d["exchange_cost_config4_band_loopback"]) == {"monolithic", "pipelined_1", "pipelined_2"}
     assert d["two_streams_own_buffers_bit_exact"] is True
     # a capturing stream is refused instead of stalling, and the capture survives the refusal
     f = d["capture_fence"]
-    assert f["rc"] == -5 and "captured" in f["message"] and f["periodic_rc_in_capture"] == 0 and f["replay_bit_exact"]
+    assert f["rc"] == -5 and f["rc_pipelined"] == -5 and "captured" in f["message"] and f["periodic_rc_in_capture"] == 0 and f["replay_bit_exact"]
 
 
 def test_exchange_argument_errors(osg, gpu):

@@ -147,6 +147,44 @@ def test_bench_watchdog_fires_with_one_json_line():
     assert p2.returncode == 0 and "alive" in p2.stdout
 
 
+def test_bench_launches_its_own_workers(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts N workers itself: one child per rank with RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, rank 0's ONE contract line relayed to stdout, everything else any rank
+    prints sent to stderr, exit status = the children's.  The parent must not have imported torch (nothing of it may touch a GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = tmp_path / "worker.py"
+    worker.write_text("import os, sys, json\n"
+                      "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+                      "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                      "assert os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') is not None\n"
+                      "print('chatter from rank %d' % r)\n"
+                      "if r == 0: print(json.dumps({'metric': 'm', 'n_gpus': w, 'argv': sys.argv[1:]}))\n"
+                      "sys.exit(int(os.environ.get('FAIL_RANK', '-1')) == r and 7 or 0)\n")
+    code = ("import sys, types; sys.path.insert(0, %r); import bench\n"
+            "rc = bench.launch_workers(types.SimpleNamespace(gpus=3), ['--gpus', '3', '--steps', '2'], script=%r)\n"
+            "assert 'torch' not in sys.modules, 'the launching parent imported torch'\n"
+            "sys.exit(rc)\n" % (root, str(worker)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "m", "n_gpus": 3, "argv": ["--gpus", "3", "--steps", "2"]}
+    assert all(f"chatter from rank {r}" in p.stderr for r in range(3))
+    # a failing worker fails the job with its status
+    p2 = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, FAIL_RANK="2"))
+    assert p2.returncode == 7
+    # and the real thing on a box without a GPU: both workers start, fail on the device assertion (not on a usage message)
+    import torch
+    if not torch.cuda.is_available():
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        p3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+        assert p3.returncode != 0 and not p3.stdout.strip()
+        assert "needs a HIP device (rank 0 of 2)" in p3.stderr and "needs a HIP device (rank 1 of 2)" in p3.stderr and "launch N > 1 with" not in p3.stderr
+
+
 def test_bench_refuses_a_strong_split_that_does_not_divide():
     """config 4 divides the 1800 rows evenly; the remainder rule for Ny % R != 0 is Oceananigans-internal (unpinned), so the
     strong-scaling bench refuses such an N before touching a device"""
@@ -156,6 +194,9 @@ def test_bench_refuses_a_strong_split_that_does_not_divide():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, WORLD_SIZE="7", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "7"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0 and "1800 % N == 0" in p.stderr and not p.stdout.strip()
+    env2 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}      # ... and so does the self-launching parent
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "7"], capture_output=True, text=True, env=env2, timeout=300)
     assert p.returncode != 0 and "1800 % N == 0" in p.stderr and not p.stdout.strip()
 
 

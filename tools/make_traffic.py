@@ -29,17 +29,24 @@ def per_kernel(path, counter):
 
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    sys.path.insert(0, ROOT)
+    from bench import sources_sha16
+    csrc = "orthogonalsphericalshellgrids.jl_amd/csrc/"
+    grid_src = [csrc + f for f in ("tpg_grid.hip", "tpg_batch.hpp", "tpg_math.hpp")]
+    fill_src = [csrc + f for f in ("tpg_zipper_kernels.hpp", "tpg_zipper.hip")]
+    sources = {"k_tables": grid_src, "k_cells_tile": grid_src, "k_cells": grid_src, "k_halos": grid_src, "k_south": grid_src,
+               "k_fill_merged": fill_src, "k_zipper_cols": fill_src, "k_periodic_x_vec": fill_src, "k_fill_fused_vec": fill_src,
+               "k_zipper_cols_copy_probe": fill_src, "k_pack": fill_src, "k_synthetic": [csrc + "tpg_testabi.hip"]}
     kernels = {}
     for k in fetch:
+        # bench.py reports a kernel's `traffic` only while the files that kernel is compiled from hash to what they were when measured
         kernels[k] = {"fetch_bytes_raw": fetch[k], "fetch_bytes_corrected": 2 * fetch[k], "write_bytes": write.get(k, 0.0),
-                      "hbm_bytes_per_launch": 2 * fetch[k] + write.get(k, 0.0)}
-    src = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "csrc", "tpg_zipper_kernels.hpp")
+                      "hbm_bytes_per_launch": 2 * fetch[k] + write.get(k, 0.0),
+                      "sources": sources.get(k, []), "sources_sha16": sources_sha16(sources[k]) if k in sources else None}
     out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc.sh) over `bench.py --no-aux --no-fill-step "
                       f"--steps 5 --warmup 1`: {os.path.relpath(sys.argv[1], ROOT)}, {os.path.relpath(sys.argv[2], ROOT)}; per-launch averages "
                       "(first launch dropped). Counter unit = KiB; FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B, "
                       "MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as read.",
-           # bench.py reports `roofline.traffic` only while the kernel source is the one these counters were taken on
-           "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
            "kernels": kernels}
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -72,6 +72,72 @@ def main():
             steady = (time.perf_counter() - t0) / 5 * 1e3
             out["cases"].append({"size": [Nx, Ny, Nz], "nfields": nf, "packed": packed, "bit_exact": good, "first_call_ms": round(ms, 3),
                                  "steady_call_ms": round(steady, 3)})
+    # ---- the PIPELINED packed exchange (tpg_halo_exchange_y_pipelined_peers): stages of k fields, the RCCL groups on a second stream;
+    #      must deliver exactly what the monolithic form delivers -- one stream and two, k = 1, 2, 3 (ragged last stage), all fields ----
+    pcases = []
+    comm_stream = torch.cuda.Stream(dev)
+    for (Nx, Ny, Nz), (Hx, Hy, Hz), nf, dt, tdt in (((48, 40, 3), (4, 4, 2), 5, np.float64, torch.float64),
+                                                   ((20, 12, 2), (3, 2, 1), 3, np.float32, torch.float32),
+                                                   ((3600, 225, 75), (4, 4, 4), 4, np.float64, torch.float64)):
+        shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
+        ft = 1 if dt == np.float64 else 0
+        nbuf = lib.tpg_y_halo_buffer_elems(nf, Nx, Nz, Hx, Hy, Hz)
+        big = Nx >= 3600                                                 # config 4's band: 2.2 GB of host data per case, fewer variants
+        for fps in ((1, 2) if big else sorted({1, 2, 3, nf})):
+            for cs in ((comm_stream,) if big else (comm_stream, None)):
+                for south, north in ((0, 0), (0, -1), (-1, 0)):
+                    hosts = [rng.uniform(-1, 1, shape).astype(dt) for _ in range(nf)]
+                    devs = [torch.from_numpy(h).to(dev) for h in hosts]
+                    bufs = [torch.full((nbuf,), float("nan"), dtype=tdt, device=dev) for _ in range(4)]
+                    stream = _lib.current_stream_ptr(dev)
+                    rcs = []
+                    for rep in range(2):                                   # twice: buffer reuse across calls on the same pair of streams
+                        rcs.append(lib.tpg_halo_exchange_y_pipelined_peers(comm.handle, south, north, _lib.ptr_table(devs), nf,
+                                                                           *[b.data_ptr() for b in bufs], Nx, Ny, Nz, Hx, Hy, Hz, ft, stream,
+                                                                           C.c_void_p(cs.cuda_stream) if cs is not None else None, fps))
+                    torch.cuda.synchronize()
+                    good = all(r_ == 0 for r_ in rcs)
+                    for h, d in zip(hosts, devs):
+                        want = h.copy()
+                        if south >= 0 and north >= 0:
+                            want[:, :Hy] = h[:, Ny:Ny + Hy]; want[:, Ny + Hy:] = h[:, Hy:2 * Hy]
+                        elif south >= 0:
+                            want[:, :Hy] = h[:, Hy:2 * Hy]                 # the one send (south) pairs the one receive (from the south)
+                        else:
+                            want[:, Ny + Hy:] = h[:, Ny:Ny + Hy]
+                        good = good and np.array_equal(d.cpu().numpy(), want)
+                    pcases.append({"size": [Nx, Ny, Nz], "nfields": nf, "fields_per_stage": fps, "two_streams": cs is not None,
+                                   "peers": [south, north], "bit_exact": bool(good)})
+                    out["ok"] = out["ok"] and good
+    out["pipelined"] = {"cases": len(pcases), "all_bit_exact": all(c["bit_exact"] for c in pcases),
+                        "failed": [c for c in pcases if not c["bit_exact"]]}
+    # cost of the two forms at config 4's band, interior rank (two seams), back to back on the loop-back (no link: RCCL's kernels copy on the device)
+    (Nx, Ny, Nz), (Hx, Hy, Hz), nf = (3600, 225, 75), (4, 4, 4), 4
+    shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
+    devs = [torch.rand(shape, dtype=torch.float64, device=dev) for _ in range(nf)]
+    nbuf = lib.tpg_y_halo_buffer_elems(nf, Nx, Nz, Hx, Hy, Hz)
+    bufs = [torch.empty(nbuf, dtype=torch.float64, device=dev) for _ in range(4)]
+    bp, ptrs, stream = [b.data_ptr() for b in bufs], _lib.ptr_table(devs), _lib.current_stream_ptr(dev)
+    csp = C.c_void_p(comm_stream.cuda_stream)
+    forms = {"monolithic": lambda: lib.tpg_halo_exchange_y_peers(comm.handle, 0, 0, ptrs, nf, *bp, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream),
+             "pipelined_1": lambda: lib.tpg_halo_exchange_y_pipelined_peers(comm.handle, 0, 0, ptrs, nf, *bp, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream, csp, 1),
+             "pipelined_2": lambda: lib.tpg_halo_exchange_y_pipelined_peers(comm.handle, 0, 0, ptrs, nf, *bp, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream, csp, 2)}
+    cost = {}
+    for name, fn in forms.items():
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        host_ms = (time.perf_counter() - t0) / 20 * 1e3
+        torch.cuda.synchronize()
+        cost[name] = {"device_ms": round(e0.elapsed_time(e1) / 20, 4), "host_enqueue_ms": round(host_ms, 4)}
+    out["exchange_cost_config4_band_loopback"] = cost
+
     # ---- tpg_fill_halo_regions_distributed_peers: the whole fill of a band in ONE call (zipper / periodic x / seams) ----------
     (Nx, Ny, Nz), (Hx, Hy, Hz) = (48, 40, 3), (4, 4, 2)
     shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
@@ -83,16 +149,21 @@ def main():
     dcases = []
     # (a) a middle band: no zipper, both seams (peers = this rank): periodic x, then south halo <- own north interior rows etc.
     # (b) the north band: zipper + periodic x, then the south seam only (south halo <- own south interior rows: the one send pairs the one recv)
-    for label, south, north, zipper in (("middle", 0, 0, 0), ("north", 0, -1, 1)):
+    for label, south, north, zipper, pipelined in (("middle", 0, 0, 0, False), ("north", 0, -1, 1, False),
+                                                   ("middle", 0, 0, 0, True), ("north", 0, -1, 1, True)):
         hosts = [rng.uniform(-1, 1, shape) for _ in specs]
         devs = [torch.from_numpy(h).to(dev) for h in hosts]
         # expected: the product's own LOCAL fill (bit-exact against the oracle in tests/test_gpu_zipper.py) + the loop-back row moves
         refs = [d.clone() for d in devs]
         _lib.check(lib.tpg_fill_halo_regions(_lib.ptr_table(refs), 4, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, zipper, 1, stream))
-        rc = lib.tpg_fill_halo_regions_distributed_peers(comm.handle, south, north, zipper, _lib.ptr_table(devs), 4, xl, yl, sg,
-                                                         bufs[0].data_ptr(), bufs[1].data_ptr() if north >= 0 else None,
-                                                         bufs[2].data_ptr(), bufs[3].data_ptr() if north >= 0 else None,
-                                                         Nx, Ny, Nz, Hx, Hy, Hz, 1, stream)
+        bargs = (bufs[0].data_ptr(), bufs[1].data_ptr() if north >= 0 else None, bufs[2].data_ptr(), bufs[3].data_ptr() if north >= 0 else None)
+        if pipelined:
+            rc = lib.tpg_fill_halo_regions_distributed_pipelined_peers(comm.handle, south, north, zipper, _lib.ptr_table(devs), 4, xl, yl, sg,
+                                                                       *bargs, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream,
+                                                                       C.c_void_p(comm_stream.cuda_stream), 1)
+        else:
+            rc = lib.tpg_fill_halo_regions_distributed_peers(comm.handle, south, north, zipper, _lib.ptr_table(devs), 4, xl, yl, sg,
+                                                             *bargs, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream)
         torch.cuda.synchronize()
         good = rc == 0
         for r, d in zip(refs, devs):
@@ -102,7 +173,7 @@ def main():
             else:
                 want[:, :Hy] = r[:, Hy:2 * Hy]
             good = good and bool(torch.equal(d, want))
-        dcases.append({"band": label, "rc": rc, "bit_exact": bool(good)})
+        dcases.append({"band": label, "pipelined": pipelined, "rc": rc, "bit_exact": bool(good)})
         out["ok"] = out["ok"] and good
     out["distributed_fill"] = dcases
 
@@ -142,14 +213,16 @@ def main():
         sp = C.c_void_p(side.cuda_stream)
         rc_fence = lib.tpg_halo_exchange_y_peers(comm.handle, 0, 0, _lib.ptr_table([d2]), 1, *[b.data_ptr() for b in bb], 16, 12, 2, 4, 4, 1, 1, sp)
         msg = lib.tpg_last_error().decode()
+        rc_fence_p = lib.tpg_halo_exchange_y_pipelined_peers(comm.handle, 0, 0, _lib.ptr_table([d2]), 1, *[b.data_ptr() for b in bb], 16, 12, 2, 4, 4, 1, 1,
+                                                             sp, C.c_void_p(comm_stream.cuda_stream), 1)
         rc_per = lib.tpg_periodic_x_fill(_lib.ptr_table([d2]), 1, 16, 12, 2, 4, 4, 1, 1, sp)        # a capturable call after the refusal
     torch.cuda.current_stream().wait_stream(side)
     g.replay()
     torch.cuda.synchronize()
     want = before.clone()
     want[:, :, :4] = before[:, :, 16:20]; want[:, :, 20:] = before[:, :, 4:8]
-    out["capture_fence"] = {"rc": rc_fence, "message": msg, "periodic_rc_in_capture": rc_per, "replay_bit_exact": bool(torch.equal(d2, want))}
-    out["ok"] = out["ok"] and rc_fence == -5 and rc_per == 0 and out["capture_fence"]["replay_bit_exact"]
+    out["capture_fence"] = {"rc": rc_fence, "rc_pipelined": rc_fence_p, "message": msg, "periodic_rc_in_capture": rc_per, "replay_bit_exact": bool(torch.equal(d2, want))}
+    out["ok"] = out["ok"] and rc_fence == -5 and rc_fence_p == -5 and rc_per == 0 and out["capture_fence"]["replay_bit_exact"]
 
     # the chain rule: a one-rank chain has no seam
     d = torch.zeros((1, 12, 12), dtype=torch.float64, device=dev)
