@@ -8,14 +8,20 @@
 # replaces (file:line in CliMA/OrthogonalSphericalShellGrids.jl v0.2.1).  Names of Oceananigans internals that the
 # reference itself does not spell out (the south/north halo launcher) are marked [recalled].
 #
-# No CUDA.jl, no KernelAbstractions / AMDGPU.jl code generation: device memory is reached through raw pointers.
-# Three hooks adapt it to the array backend in use: `device_pointer`, `current_stream`, `device_array`.
+# No CUDA.jl, no KernelAbstractions / AMDGPU.jl code generation.  Device memory is OWNED here: `HIPArray` (section 1b) is a
+# minimal DenseArray over hipMalloc / hipFree / hipMemcpy, called through `ccall` on libamdhip64, and `HIPGPU()` is the
+# Oceananigans architecture value that carries it.  `device_pointer` accepts nothing but (views / OffsetArrays of) a HIPArray: no
+# path in this file can hand a host pointer or a CuArray to a `tpg_*` entry point.
 module TripolarHIP
 
 export TripolarGrid, ZipperBoundaryCondition           # src/OrthogonalSphericalShellGrids.jl:4
+export HIPArray, HIPGPU                                # device memory + architecture of this binding (no reference counterpart)
 
 using Oceananigans
-using Oceananigans.Architectures: AbstractArchitecture, architecture, child_architecture, on_architecture, array_type
+using Oceananigans.Architectures: AbstractArchitecture, CPU, child_architecture
+import Oceananigans.Architectures: architecture, on_architecture, array_type
+using Oceananigans.Grids: AbstractGrid
+using Oceananigans.DistributedComputations: DistributedGrid
 using Oceananigans.Grids: R_Earth, Center, Face, Periodic, Bounded, RightConnected, FullyConnected,
                           OrthogonalSphericalShellGrid, generate_coordinate, halo_size, topology, cpu_face_constructor_z
 using Oceananigans.ImmersedBoundaries: ImmersedBoundaryGrid
@@ -35,6 +41,7 @@ import Oceananigans.Grids: x_domain, y_domain, with_halo
 import Oceananigans.DistributedComputations: reconstruct_global_grid
 
 const libtripolar = get(ENV, "LIBTRIPOLAR_HIP", "libtripolar_hip.so")
+const libhip      = get(ENV, "LIBAMDHIP64", "libamdhip64.so")      # the HIP runtime itself (/opt/rocm/lib); plain C entry points only
 
 # ---------------------------------------------------------------------------------------------------------------------
 # 1. C structs / status handling (include/tripolar_hip.h)
@@ -67,13 +74,150 @@ function check(status::Cint)
     throw(TripolarHIPError(status, msg))
 end
 
+# ---------------------------------------------------------------------------------------------------------------------
+# 1b. Device memory without CUDA.jl / AMDGPU.jl: HIPArray, HIPGPU            replaces on_architecture(arch, map(FT, A)) x 20,
+#                                                                             src/tripolar_grid.jl:303-328
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference builds its 20 arrays on the CPU and hands them over with `on_architecture(arch, ...)`, which for Oceananigans'
+# `GPU()` means CuArray (CUDA.jl) -- absent on an MI355X host -- and for `CPU()` a host Array whose pointer a HIP kernel must never
+# see.  Here the arrays are born in HBM: `HIPArray{T,N}` owns one hipMalloc allocation (freed by a finalizer through hipFree) and
+# is all the array type this path needs -- size / pointer / unsafe_convert for `ccall`, copies to and from host Arrays through
+# hipMemcpy, `Adapt` rules; scalar indexing is refused (it would be a PCIe round trip per element).  Prototypes as in
+# /opt/rocm/include/hip/hip_runtime_api.h (checked statically by tests/test_julia_glue_static.py):
+#   hipError_t hipMalloc(void** ptr, size_t size);             hipError_t hipFree(void* ptr);
+#   hipError_t hipMemcpy(void* dst, const void* src, size_t sizeBytes, hipMemcpyKind kind);
+#   hipError_t hipMemset(void* dst, int value, size_t sizeBytes);
+#   hipError_t hipStreamCreateWithFlags(hipStream_t* stream, unsigned int flags);
+#   hipError_t hipStreamSynchronize(hipStream_t stream);       hipError_t hipDeviceSynchronize(void);
+#   const char* hipGetErrorString(hipError_t hipError);
+const hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice = Cint(1), Cint(2), Cint(3)   # enum hipMemcpyKind
+const hipStreamNonBlocking = Cuint(1)
+
+function hipcheck(status::Cint)
+    status == 0 && return nothing
+    throw(TripolarHIPError(status, unsafe_string(ccall((:hipGetErrorString, libhip), Cstring, (Cint,), status))))
+end
+
+mutable struct HIPArray{T, N} <: DenseArray{T, N}
+    ptr::Ptr{Cvoid}                    # device address (hipMalloc); C_NULL once freed or for an empty array
+    dims::NTuple{N, Int}
+    function HIPArray{T, N}(::UndefInitializer, dims::NTuple{N, Int}) where {T, N}
+        isbitstype(T) || throw(ArgumentError("HIPArray: element type $T is not a plain bits type"))
+        nbytes = prod(dims) * sizeof(T)
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        nbytes > 0 && hipcheck(ccall((:hipMalloc, libhip), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, nbytes))
+        a = new{T, N}(p[], dims)
+        finalizer(unsafe_free!, a)
+        return a
+    end
+end
+
+"return the allocation to the HIP runtime now (idempotent; also the finalizer)"
+function unsafe_free!(a::HIPArray)
+    a.ptr == C_NULL || ccall((:hipFree, libhip), Cint, (Ptr{Cvoid},), a.ptr)       # status ignored: a finalizer must not throw
+    a.ptr = C_NULL
+    return nothing
+end
+
+HIPArray{T, N}(::UndefInitializer, dims::Vararg{Integer, N}) where {T, N} = HIPArray{T, N}(undef, map(Int, dims))
+HIPArray{T}(::UndefInitializer, dims::NTuple{N, Integer}) where {T, N} = HIPArray{T, N}(undef, map(Int, dims))
+HIPArray{T}(::UndefInitializer, dims::Integer...) where {T} = HIPArray{T}(undef, dims)
+HIPArray(a::Array{T, N}) where {T, N} = copyto!(HIPArray{T, N}(undef, size(a)), a)
+HIPArray{T}(a::Array{S, N}) where {T, S, N} = HIPArray(convert(Array{T, N}, a))
+Base.Array(a::HIPArray{T, N}) where {T, N} = copyto!(Array{T, N}(undef, size(a)), a)
+
+Base.size(a::HIPArray) = a.dims
+Base.sizeof(a::HIPArray{T}) where {T} = prod(a.dims) * sizeof(T)
+Base.elsize(::Type{<:HIPArray{T}}) where {T} = sizeof(T)
+Base.pointer(a::HIPArray{T}) where {T} = Ptr{T}(a.ptr)                              # a DEVICE address: for ccall only
+Base.unsafe_convert(::Type{Ptr{T}}, a::HIPArray{T}) where {T} = Ptr{T}(a.ptr)
+Base.unsafe_convert(::Type{Ptr{Cvoid}}, a::HIPArray) = a.ptr
+Base.similar(a::HIPArray, ::Type{T}, dims::Dims{N}) where {T, N} = HIPArray{T, N}(undef, dims)
+Base.getindex(::HIPArray, I...) = error("HIPArray: scalar indexing reads device memory element by element; copy with Array(a) first")
+Base.setindex!(::HIPArray, v, I...) = error("HIPArray: scalar indexing writes device memory element by element; use copyto!(a, host_array)")
+Base.show(io::IO, a::HIPArray{T, N}) where {T, N} = print(io, join(a.dims, "x"), " HIPArray{", T, ",", N, "} @ ", a.ptr)
+Base.show(io::IO, ::MIME"text/plain", a::HIPArray) = show(io, a)
+
+# copies are synchronous (hipMemcpy on the null stream): they order themselves after every kernel this library enqueued
+function Base.copyto!(dst::HIPArray{T}, src::Array{T}) where {T}
+    length(dst) == length(src) || throw(DimensionMismatch("copyto!: $(size(src)) -> $(size(dst))"))
+    GC.@preserve dst src hipcheck(ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint),
+                                        dst.ptr, pointer(src), sizeof(src), hipMemcpyHostToDevice))
+    return dst
+end
+function Base.copyto!(dst::Array{T}, src::HIPArray{T}) where {T}
+    length(dst) == length(src) || throw(DimensionMismatch("copyto!: $(size(src)) -> $(size(dst))"))
+    GC.@preserve dst src hipcheck(ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint),
+                                        pointer(dst), src.ptr, sizeof(dst), hipMemcpyDeviceToHost))
+    return dst
+end
+function Base.copyto!(dst::HIPArray{T}, src::HIPArray{T}) where {T}
+    length(dst) == length(src) || throw(DimensionMismatch("copyto!: $(size(src)) -> $(size(dst))"))
+    GC.@preserve dst src hipcheck(ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint),
+                                        dst.ptr, src.ptr, sizeof(dst), hipMemcpyDeviceToDevice))
+    return dst
+end
+Base.copy(a::HIPArray{T, N}) where {T, N} = copyto!(HIPArray{T, N}(undef, size(a)), a)
+function Base.fill!(a::HIPArray{T}, v) where {T}                                       # zeros only need hipMemset; other values go through the host
+    if iszero(v)
+        sizeof(a) > 0 && hipcheck(ccall((:hipMemset, libhip), Cint, (Ptr{Cvoid}, Cint, Csize_t), a.ptr, 0, sizeof(a)))
+        return a
+    end
+    return copyto!(a, fill(convert(T, v), size(a)))
+end
+device_synchronize() = hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+
+# host <-> device conversion rules (what `on_architecture` and Adapt-based constructors use)
+Adapt.adapt_storage(::Type{<:HIPArray}, a::Array) = HIPArray(a)
+Adapt.adapt_storage(::Type{<:Array}, a::HIPArray) = Array(a)
+Adapt.adapt_storage(::Type{<:HIPArray}, a::HIPArray) = a
+
+"""
+    HIPGPU()
+
+The Oceananigans architecture value of this binding: one MI355X reached through the HIP runtime and libtripolar_hip, with
+`HIPArray` as its array type.  `TripolarGrid(HIPGPU(); size = ...)` (and `Distributed(HIPGPU(); partition = Partition(1, R))`)
+builds the grid in HBM; `on_architecture(CPU(), grid)` brings it back.  Oceananigans' own `GPU()` is CUDA.jl's (0.95-0.99) and
+is refused by `device_array`; `CPU()` is refused as well (a host pointer must never reach a HIP kernel).
+"""
+struct HIPGPU <: AbstractArchitecture end
+array_type(::HIPGPU) = HIPArray                                                        # [recalled: Oceananigans.Architectures.array_type]
+architecture(::HIPArray) = HIPGPU()
+on_architecture(::HIPGPU, a::Array) = HIPArray(a)
+on_architecture(::HIPGPU, a::HIPArray) = a
+on_architecture(::CPU, a::HIPArray) = Array(a)
+on_architecture(arch::HIPGPU, a::OffsetArray) = OffsetArray(on_architecture(arch, parent(a)), a.offsets...)
+on_architecture(arch::HIPGPU, a::AbstractRange) = on_architecture(arch, collect(a))
+
 # backend hooks -------------------------------------------------------------------------------------------------------
-device_pointer(a) = Ptr{Cvoid}(UInt(pointer(parent(a))))         # raw HBM address of the parent array
-current_stream() = C_NULL                                         # hipStream_t of the task; NULL = default stream
+# raw HBM address of the memory behind `a`: a HIPArray, or an OffsetArray / reshape whose root parent is one.
+# Anything else -- a host Array, a CuArray, a ROCArray this file did not allocate -- is refused: the C ABI dereferences the
+# address on the device.
+device_pointer(a::HIPArray) = (a.ptr == C_NULL && length(a) > 0) ? error("HIPArray used after unsafe_free!") : a.ptr
+device_pointer(a::OffsetArray) = device_pointer(parent(a))
+device_pointer(a::Base.ReshapedArray) = device_pointer(parent(a))
+device_pointer(a) = throw(ArgumentError("libtripolar_hip needs device memory owned by a HIPArray (HIPGPU() architecture); got $(typeof(a)): " *
+                                        "host Arrays and CuArrays are refused"))
+
+# hipStream_t of the calling Julia task: one non-blocking stream per task, created at first use (fills issued from different
+# tasks run on different streams and never share seam buffers, section 5); `use_default_stream!()` selects the NULL stream instead
+const TASK_STREAMS = IdDict{Any, Ptr{Cvoid}}()
+const USE_DEFAULT_STREAM = Ref(true)
+use_default_stream!(flag::Bool = true) = (USE_DEFAULT_STREAM[] = flag)
+function new_stream()
+    s = Ref{Ptr{Cvoid}}(C_NULL)
+    hipcheck(ccall((:hipStreamCreateWithFlags, libhip), Cint, (Ref{Ptr{Cvoid}}, Cuint), s, hipStreamNonBlocking))
+    return s[]
+end
+current_stream() = USE_DEFAULT_STREAM[] ? C_NULL : get!(new_stream, TASK_STREAMS, current_task())
+synchronize_stream(s = current_stream()) = hipcheck(ccall((:hipStreamSynchronize, libhip), Cint, (Ptr{Cvoid},), s))
+
 # An UNINITIALISED device array (HBM) of that shape: tpg_build_grid overwrites every element of the 20 arrays, halos included,
-# so nothing is zeroed on the host and nothing crosses PCIe.  `array_type(arch)` is Oceananigans' own arch -> array-type map
-# [recalled: Oceananigans.Architectures.array_type, Array for CPU(), the device array type for GPU()].
-device_array(arch, FT, dims...) = array_type(child_architecture(arch)){FT}(undef, dims...)
+# so nothing is zeroed on the host and nothing crosses PCIe.
+device_array(::HIPGPU, FT, dims...) = HIPArray{FT}(undef, dims...)
+device_array(arch::Distributed, FT, dims...) = device_array(child_architecture(arch), FT, dims...)
+device_array(arch, FT, dims...) = throw(ArgumentError("TripolarHIP builds grids on HIPGPU() (or Distributed(HIPGPU(); ...)) only; got $(typeof(arch)): " *
+                                                      "Oceananigans' GPU() is CUDA.jl's and CPU() memory cannot be given to a HIP kernel"))
 
 # ---------------------------------------------------------------------------------------------------------------------
 # 2. Tripolar mapping record, grid aliases            src/tripolar_grid.jl:6-17,371; distributed_tripolar_grid.jl:12-15
@@ -127,12 +271,13 @@ function build_band(arch, FT, size, halo, southernmost_latitude, radius, z, nort
 end
 
 """
-    TripolarGrid(arch = CPU(), FT = Float64; size, southernmost_latitude = -80, halo = (4, 4, 4),
+    TripolarGrid(arch = HIPGPU(), FT = Float64; size, southernmost_latitude = -80, halo = (4, 4, 4),
                  radius = R_Earth, z = (0, 1), north_poles_latitude = 55, first_pole_longitude = 70)
 
-Same keywords, defaults, return type and `ArgumentError` as src/tripolar_grid.jl:59-66,81-83,304-330.
+Same keywords, defaults, return type and `ArgumentError` as src/tripolar_grid.jl:59-66,81-83,304-330; the default architecture
+is `HIPGPU()` (the reference's is `CPU()`, which this binding refuses: see `device_array`).
 """
-function TripolarGrid(arch::AbstractArchitecture = CPU(), FT::DataType = Float64; size, southernmost_latitude = -80,
+function TripolarGrid(arch::AbstractArchitecture = HIPGPU(), FT::DataType = Float64; size, southernmost_latitude = -80,
                       halo = (4, 4, 4), radius = R_Earth, z = (0, 1), north_poles_latitude = 55, first_pole_longitude = 70)
     return build_band(arch, FT, size, halo, southernmost_latitude, radius, z, north_poles_latitude,
                       first_pole_longitude, 1, size[2], RightConnected)
@@ -385,11 +530,21 @@ The C-ABI part of one `fill_halo_regions!`, one batched call per geometry group.
   :zipper    the fold alone                     tpg_zipper_fill            (fold_north_*!, src/zipper_boundary_condition.jl:70-155)
   :periodic  periodic x (-> seams)              tpg_periodic_x_fill (+ tpg_halo_exchange_y)
 """
+const TPG_MAX_FIELDS = 16                      # include/tripolar_hip.h: fields per seam message / per distributed call
+# Seam exchange form of distributed fills: 0 = monolithic (pack all -> ONE RCCL group -> unpack all); k > 0 = pipelined in stages of
+# k fields with the RCCL groups on a second stream (tpg_fill_halo_regions_distributed_pipelined); identical results
+const SEAM_FIELDS_PER_STAGE = Ref(0)
+seam_exchange_pipelined!(fields_per_stage::Integer = 1) = (SEAM_FIELDS_PER_STAGE[] = Int(fields_per_stage))
+const COMM_STREAMS = IdDict{Any, Ptr{Cvoid}}()                  # the second stream of the pipelined exchange, one per Julia task
+comm_stream() = get!(new_stream, COMM_STREAMS, current_task())
+
 function hip_fill!(fields, bcs, locs, indices, grid; stage::Symbol, comm = nothing, arch = nothing)
     Nx, Ny, _ = size(grid)
     Hx, Hy, _ = halo_size(grid)
     zips = comm === nothing || comm.rank == comm.nranks - 1                     # the fold lives on the serial grid / the last rank
-    for ((FT, Nz, Hz), idx) in fill_groups(fields, locs, indices, grid)
+    for ((FT, Nz, Hz), group) in fill_groups(fields, locs, indices, grid)
+      # one seam message holds at most TPG_MAX_FIELDS fields: a larger group goes in batches (as HaloFillPlan does in fields.py)
+      for idx in Iterators.partition(group, TPG_MAX_FIELDS)
         fs   = [fields[n] for n in idx]
         ptrs = Ptr{Cvoid}[device_pointer(f) for f in fs]
         xloc = Int8[loc_code(locs[n][1]) for n in idx]
@@ -398,6 +553,7 @@ function hip_fill!(fields, bcs, locs, indices, grid; stage::Symbol, comm = nothi
         bufs = comm === nothing ? ntuple(_ -> nothing, 4) : seam_buffers(arch, grid, length(fs), FT, Nz, Hz)
         bp   = map(b -> b === nothing ? C_NULL : device_pointer(b), bufs)
         s    = current_stream()
+        fps  = SEAM_FIELDS_PER_STAGE[]
         GC.@preserve fs bufs begin
             if stage === :zipper
                 zips && check(ccall((:tpg_zipper_fill, libtripolar), Cint,
@@ -407,15 +563,29 @@ function hip_fill!(fields, bcs, locs, indices, grid; stage::Symbol, comm = nothi
                 check(ccall((:tpg_periodic_x_fill, libtripolar), Cint,
                             (Ptr{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
                             ptrs, length(fs), Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), s))
-                comm === nothing || check(ccall((:tpg_halo_exchange_y, libtripolar), Cint,
+                if comm !== nothing && fps > 0
+                    check(ccall((:tpg_halo_exchange_y_pipelined, libtripolar), Cint,
+                            (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                             Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                            comm.handle, comm.rank, comm.nranks, ptrs, length(fs), bp[1], bp[2], bp[3], bp[4],
+                            Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), s, comm_stream(), fps))
+                elseif comm !== nothing
+                    check(ccall((:tpg_halo_exchange_y, libtripolar), Cint,
                             (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
                              Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
                             comm.handle, comm.rank, comm.nranks, ptrs, length(fs), bp[1], bp[2], bp[3], bp[4],
                             Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), s))
+                end
             elseif comm === nothing                                              # :all, serial grid: ONE launch (fused / merged)
                 check(ccall((:tpg_fill_halo_regions, libtripolar), Cint,
                             (Ptr{Ptr{Cvoid}}, Cint, Ptr{Int8}, Ptr{Int8}, Ptr{Int32}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
                             ptrs, length(fs), xloc, yloc, sgn, Nx, Ny, Nz, Hx, Hy, Hz, 1, ft_code(FT), s))
+            elseif fps > 0                                                       # :all, latitude band, pipelined seam exchange
+                check(ccall((:tpg_fill_halo_regions_distributed_pipelined, libtripolar), Cint,
+                            (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Int8}, Ptr{Int8}, Ptr{Int32},
+                             Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                            comm.handle, comm.rank, comm.nranks, ptrs, length(fs), xloc, yloc, sgn, bp[1], bp[2], bp[3], bp[4],
+                            Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), s, comm_stream(), fps))
             else                                                                 # :all, latitude band: zipper (last rank) -> periodic x -> RCCL seams
                 check(ccall((:tpg_fill_halo_regions_distributed, libtripolar), Cint,
                             (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Int8}, Ptr{Int8}, Ptr{Int32},
@@ -424,6 +594,7 @@ function hip_fill!(fields, bcs, locs, indices, grid; stage::Symbol, comm = nothi
                             Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), s))
             end
         end
+      end
     end
     return nothing
 end
@@ -438,14 +609,20 @@ zipper_fill!(fields, north_bcs, locs, grid; periodic_x::Bool = false) =
 const OBC = Oceananigans.BoundaryConditions
 side(c, bs, f) = c isa Tuple ? map(f, bs) : f(bs[1])                          # tupled fill: tuples of conditions; single field: one
 south_only!(c, bs, indices, loc, arch, grid, args...; kwargs...) =
-    OBC.fill_halo_event!(c, OBC.fill_south_and_north_halo!, (side(c, bs, b -> b.south), side(c, bs, _ -> nothing)), indices, loc, arch, grid, args...; kwargs...)
+    OBC.fill_halo_event!(c, OBC.fill_south_and_north_halo!, (side(c, bs, b -> fills_south(b.south) ? b.south : nothing), side(c, bs, _ -> nothing)), indices, loc, arch, grid, args...; kwargs...)
 bottom_and_top!(c, bs, indices, loc, arch, grid, args...; kwargs...) =
     OBC.fill_halo_event!(c, OBC.fill_bottom_and_top_halo!, (side(c, bs, b -> b.bottom), side(c, bs, b -> b.top)), indices, loc, arch, grid, args...; kwargs...)
+
+is_communication(bc) = bc isa BoundaryCondition{<:Oceananigans.BoundaryConditions.DistributedCommunication}   # [recalled classification name; alias DCBC]
+fills_south(bc) = !isnothing(bc) && !is_communication(bc)
 
 function tripolar_fill!(c, bcs, indices, loc, grid, comm, args...; kwargs...)
     arch = architecture(grid)
     cs, bs, ls = as_tuple(c), as_tuple(bcs), c isa Tuple ? loc : (loc,)
-    any(b -> !isnothing(b.south), bs) && south_only!(c, bs, indices, loc, arch, grid, args...; kwargs...)   # src/tripolar_grid.jl:148: `nothing` in the reference's own fills
+    # Oceananigans' own south fill, for a south condition that is a real one: not `nothing` (src/tripolar_grid.jl:148: the reference's own
+    # fills) and not the halo-communication condition injected on ranks > 0 (src/distributed_tripolar_grid.jl:171) -- that side is a seam,
+    # filled by the RCCL exchange inside the C call; driving Oceananigans' south/north launcher with it would take the MPI path
+    any(b -> fills_south(b.south), bs) && south_only!(c, bs, indices, loc, arch, grid, args...; kwargs...)
     if all(b -> isnothing(b.bottom) && isnothing(b.top), bs)
         hip_fill!(cs, bs, ls, indices, grid; stage = :all, comm, arch)                      # one C call: fused / merged launch (+ seams)
     else
@@ -458,10 +635,14 @@ end
 
 import Oceananigans.BoundaryConditions: fill_halo_regions!
 
-# serial tripolar grid: single field (c::OffsetArray, bcs::FieldBoundaryConditions) and the tupled fill (tuples of both)
+# serial tripolar grid: single field (c::OffsetArray, bcs::FieldBoundaryConditions) and the tupled fill (tuples of both).
+# Fields the C ABI cannot take (non-periodic x, (x, y)-windowed indices, a non-Zipper north side) go to Oceananigans' GENERIC method
+# through `invoke`.  `invoke` needs a signature the generic method is applicable to and this method is not: the generic one is declared on
+# `c::Union{OffsetArray, NTuple{<:Any, OffsetArray}}` with an untyped grid [recalled], so (typeof(c), ..., AbstractGrid, ...) selects it --
+# `AbstractGrid` is not a subtype of TRG, hence never this method again; an all-`Any` signature would match no method at all.
 function fill_halo_regions!(c::Union{OffsetArray, NTuple{N, OffsetArray} where N}, bcs, indices, loc, grid::TRG, args...; kwargs...)
     all(b -> hip_fill_applies(b, indices, true), as_tuple(bcs)) ||
-        return invoke(fill_halo_regions!, Tuple{Any, Any, Any, Any, Any, Vararg{Any}}, c, bcs, indices, loc, grid, args...; kwargs...)
+        return invoke(fill_halo_regions!, Tuple{typeof(c), Any, Any, Any, AbstractGrid, Vararg{Any}}, c, bcs, indices, loc, grid, args...; kwargs...)
     return tripolar_fill!(c, bcs, indices, loc, grid, nothing, args...; kwargs...)
 end
 
@@ -472,7 +653,7 @@ function fill_halo_regions!(c::Union{OffsetArray, NTuple{N, OffsetArray} where N
     arch = architecture(grid)
     last = arch.local_rank == ranks(arch.partition)[2] - 1
     all(b -> hip_fill_applies(b, indices, last), as_tuple(bcs)) ||
-        return invoke(fill_halo_regions!, Tuple{Any, Any, Any, Any, Any, Any, Vararg{Any}}, c, bcs, indices, loc, grid, buffers, args...; kwargs...)
+        return invoke(fill_halo_regions!, Tuple{typeof(c), Any, Any, Any, DistributedGrid, Any, Vararg{Any}}, c, bcs, indices, loc, grid, buffers, args...; kwargs...)
     return tripolar_fill!(c, bcs, indices, loc, grid, seam_comm(arch), args...; kwargs...)
 end
 
