@@ -268,6 +268,12 @@ def main():
             raise SystemExit(f"--scaling strong needs {NY} % N == 0 (N = {args.gpus}); use N in 1,2,3,4,5,6,8,... or --scaling weak")
         sys.exit(launch_workers(args, sys.argv[1:]))
 
+    # Whatever a library prints on stdout (RCCL writes a version banner there when a communicator comes up) must not reach OUR stdout:
+    # the contract is ONE JSON line.  File descriptor 1 is pointed at stderr for the rest of the process; the line goes to a saved copy.
+    contract_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     if not (os.path.exists(LIB) and os.path.exists(os.path.join(ROOT, "tools", "libtripolar_hip_test.so"))):
@@ -735,7 +741,8 @@ def main():
                     "stream is %.0f %%%% of HBM peak" % (tflops, FP64_VALU_PEAK_TFLOPS, 100 * 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS)}
         if not chain and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line))          # ASCII-escaped: safe under any stdout encoding
+        contract_out.write(json.dumps(line) + "\n")          # ASCII-escaped: safe under any stdout encoding
+        contract_out.flush()
     if chain:
         if world > 1:
             dist.barrier()

@@ -25,8 +25,8 @@
  *  - element type selected by `ft`: TPG_F32 or TPG_F64.
  *
  *
- * The library reads no environment variable and holds no mutable global state beyond a thread-local error string and the
- * lazily bound librccl entry points (std::call_once).  Test / bench hooks (synthetic fill, the copy probe of the fold, the
+ * The library reads no environment variable and holds no mutable global state beyond a thread-local error string, the
+ * lazily bound librccl entry points (std::call_once) and a thread-local pool of ordering events for the pipelined exchange.  Test / bench hooks (synthetic fill, the copy probe of the fold, the
  * elementary-function probe) and the TPG_* cross-check knobs that force the fallback kernels live in a separate
  * library, libtripolar_hip_test.so (include/tripolar_hip_test.h), which a host never loads.
  */
@@ -221,7 +221,7 @@ int tpg_halo_exchange_y_peers(void *comm, int south_peer, int north_peer, void *
  * form delivers (same pack / unpack kernels on slices).  On return `stream` is ordered after every transfer and unpack, and
  * comm_stream holds no work `stream` does not wait for.  comm_stream: a second hipStream_t of the caller on the same device
  * (NULL or == stream: the same stages on one stream, no overlap).  All four message buffers are required for every side
- * with a peer (no pack-free form).  The ordering events are created and destroyed inside the call. */
+ * with a peer (no pack-free form).  The ordering events come from a thread-local pool (created at a thread's first call). */
 int tpg_halo_exchange_y_pipelined(void *comm, int rank, int nranks, void *const fields[], int nfields,
                                   void *send_south, void *send_north, void *recv_south, void *recv_north,
                                   int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,

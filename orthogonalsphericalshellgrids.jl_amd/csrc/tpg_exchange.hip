@@ -228,8 +228,7 @@ int tpg_halo_exchange_y_peers(void* comm, int south_peer, int north_peer, void* 
 // delivered is bit-identical to the monolithic form (same pack / unpack kernels on slices).  When the function returns, `stream`
 // is ordered after every transfer and unpack (its last wait), and comm_stream holds no work that `stream` does not wait for: the
 // message buffers may be reused by the next call on the same pair of streams.  comm_stream = NULL (or = stream) runs the same
-// stages on the one stream (no overlap).  The events that order the two streams are created and destroyed inside the call
-// (timing disabled); the library keeps nothing.
+// stages on the one stream (no overlap).  The events that order the two streams come from a thread-local pool (timing disabled).
 int tpg_halo_exchange_y_pipelined_peers(void* comm, int south_peer, int north_peer, void* const fields[], int nfields,
                                         void* send_south, void* send_north, void* recv_south, void* recv_north,
                                         int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
@@ -255,18 +254,21 @@ int tpg_halo_exchange_y_pipelined_peers(void* comm, int south_peer, int north_pe
     const size_t per_field = tpg_y_halo_buffer_elems(1, Nx, Nz, Hx, Hy, Hz);
     auto slice = [&](void* base, int f0) -> void* { return base ? static_cast<char*>(base) + (size_t)f0 * per_field * esz : nullptr; };
 
-    hipEvent_t packed_ev[TPG_MAX_FIELDS], moved_ev[TPG_MAX_FIELDS];
-    int nev = 0;
-    auto destroy_events = [&]() { for (int k = 0; k < nev; ++k) { (void)hipEventDestroy(packed_ev[k]); (void)hipEventDestroy(moved_ev[k]); } nev = 0; };
+    // ordering events: a thread-local pool (timing disabled), grown on demand and kept for the life of the thread -- creating and
+    // destroying 2 x stages events per fill cost more host time than the RCCL groups themselves.  Re-recording an event does not
+    // disturb a wait enqueued on it earlier (the wait took the state it had then).
+    hipEvent_t *packed_ev = nullptr, *moved_ev = nullptr;
     if (two) {
-        for (int k = 0; k < nstages; ++k) {
-            hipError_t e1 = hipEventCreateWithFlags(&packed_ev[k], hipEventDisableTiming);
-            if (e1 != hipSuccess) { destroy_events(); return tpg::hip_status(e1, "hipEventCreateWithFlags"); }
-            hipError_t e2 = hipEventCreateWithFlags(&moved_ev[k], hipEventDisableTiming);
-            if (e2 != hipSuccess) { (void)hipEventDestroy(packed_ev[k]); destroy_events(); return tpg::hip_status(e2, "hipEventCreateWithFlags"); }
-            nev = k + 1;
+        static thread_local hipEvent_t pool[2 * TPG_MAX_FIELDS];
+        static thread_local int pooled = 0;
+        while (pooled < 2 * TPG_MAX_FIELDS) {                  // once per thread
+            const hipError_t ee = hipEventCreateWithFlags(&pool[pooled], hipEventDisableTiming);
+            if (ee != hipSuccess) return tpg::hip_status(ee, "hipEventCreateWithFlags");
+            ++pooled;
         }
+        packed_ev = pool; moved_ev = pool + TPG_MAX_FIELDS;
     }
+    auto destroy_events = []() {};
 #define TPG_PIPE_CHECK(expr) do { if ((rc = (expr))) { destroy_events(); return rc; } } while (0)
     // every pack first: they depend on nothing but the local fill that precedes the call on `stream`
     for (int k = 0; k < nstages; ++k) {
@@ -298,7 +300,6 @@ int tpg_halo_exchange_y_pipelined_peers(void* comm, int south_peer, int north_pe
         if (north_peer >= 0) TPG_PIPE_CHECK(tpg_unpack_y_halo(fields + f0, n, slice(recv_north, f0), 1, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream));
     }
 #undef TPG_PIPE_CHECK
-    destroy_events();      // recorded and waited-for events release their resources when they complete
     return TPG_OK;
 }
 
