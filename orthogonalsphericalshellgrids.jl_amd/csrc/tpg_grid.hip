@@ -588,7 +588,12 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int ty = blockIdx.y;
+    // Tile rows are dispatched in blockIdx.y order.  The NORTHERNMOST tile row goes first: on a band that holds row Ny its top wave
+    // takes the general (scalar, branchy) path through coord() -- fold, row-Ny substitution, poles -- and is several times slower than a
+    // fast-path wave; dispatched last it was a ~10 us tail of the whole launch (a 225-row north band built in 89 us against 77 us for
+    // a middle band, round 4), dispatched first it hides behind the other tiles.  The southernmost row (row 0 of a south band: the
+    // other general-path row) follows as blockIdx.y = 1.
+    const int ty = blockIdx.y == 0 ? (int)gridDim.y - 1 : (int)blockIdx.y - 1;
     const int tx = blockIdx.x;
     const int s0 = g.jm_lo - 1 + ty * (R - 1);
     const int s = s0 + p;                                                    // this wave's step
@@ -827,6 +832,10 @@ int check_params(const tpg_params* p)
         tpg::set_error("latitude band %d:%d outside 1:%d", p->jstart, p->jend, p->Ny);
         return TPG_ERR_BAD_PARTITION;
     }
+    if (p->reserved & ~TPG_BUILD_TABLES_VALID) {
+        tpg::set_error("tpg_params.reserved: unknown flag bits 0x%x", p->reserved & ~TPG_BUILD_TABLES_VALID);
+        return TPG_ERR_INVALID_ARGUMENT;
+    }
     if (!(p->radius > 0) || !(p->north_poles_latitude < 90) || !(p->southernmost_latitude < 90)) {
         tpg::set_error("invalid radius / latitudes");
         return TPG_ERR_INVALID_ARGUMENT;
@@ -906,9 +915,11 @@ int tpg_build_grid(const tpg_params* p, void* const out[TPG_NUM_ARRAYS], void* w
     t.Nx = p->Nx; t.Ny = p->Ny; t.Hy = p->Hy; t.shift = p->Nx / 4; t.ft = p->ft;
     t.south = p->southernmost_latitude; t.npl = p->north_poles_latitude; t.R = p->radius;
     t.ti = w; t.tj = w + 4 * (size_t)p->Nx; t.ts = t.tj + 4 * (size_t)p->Ny;
-    int nt = p->Nx + 2 * p->Ny + p->Hy + 1;
-    hipLaunchKernelGGL(k_tables, dim3((nt + 63) / 64), dim3(64), 0, s, t);
-    if ((rc = tpg::launch_status("k_tables"))) return rc;
+    if (!(p->reserved & TPG_BUILD_TABLES_VALID)) {       // the caller may vouch for tables left in the workspace by an earlier call
+        int nt = p->Nx + 2 * p->Ny + p->Hy + 1;
+        hipLaunchKernelGGL(k_tables, dim3((nt + 63) / 64), dim3(64), 0, s, t);
+        if ((rc = tpg::launch_status("k_tables"))) return rc;
+    }
 
     GridK g;
     g.Nx = p->Nx; g.Ny = p->Ny; g.Hx = p->Hx; g.Hy = p->Hy; g.shift = p->Nx / 4;

@@ -88,6 +88,9 @@ def test_build_grid_argument_errors_without_device_work(osg):
     assert lib.tpg_build_grid_workspace_bytes(C.byref(p)) >= 8 * (4 * 60 + 4 * 30 + 5 * 5)
     p = _params(osg, Hy=40)
     assert lib.tpg_build_grid(C.byref(p), out, None, 0, None) == -5          # halo larger than the grid
+    p = _params(osg)
+    p.reserved = 6                                                            # only TPG_BUILD_TABLES_VALID (1) is a known flag
+    assert lib.tpg_build_grid(C.byref(p), out, None, 0, None) == -1 and b"unknown flag" in lib.tpg_last_error()
 
 
 def test_zipper_argument_errors_without_device_work(osg):

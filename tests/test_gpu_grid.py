@@ -261,3 +261,36 @@ def test_arrays_beyond_4_GiB_take_the_64_bit_offsets(osg, gpu):
             assert torch.equal(getattr(band, name), getattr(big, name)[j0 - 1:j1 + 2 * halo[1]]), (r, name)
     del big
     torch.cuda.empty_cache()
+
+
+def test_tables_valid_flag_skips_the_table_kernel_and_changes_nothing(osg, gpu):
+    """tpg_params.reserved = TPG_BUILD_TABLES_VALID: the workspace holds the 1-D tables of an earlier build of the same (Nx, Ny, Hy, ft,
+    latitudes, radius); bands, Hx and first_pole_longitude may differ.  Every array must equal the build without the flag bit for bit --
+    here 3 bands of a 360 x 180 grid built after ONE table pass, against their own full builds, f64 and f32; a poisoned workspace shows the
+    flag really skips the kernel (garbage tables -> garbage grid)."""
+    import ctypes as C
+    lib, L = osg._lib.lib(), osg._lib
+    Nx, Ny, H = 360, 180, 4
+    for ft, tdt in ((L.TPG_F64, torch.float64), (L.TPG_F32, torch.float32)):
+        def params(jstart, jend, flags, Hx=H, fpl=70.0):
+            return L.TpgParams(Nx, Ny, 3, Hx, H, H, -80.0, 55.0, fpl, osg.R_Earth, ft, jstart, jend, flags)
+        p0 = params(1, Ny, 0)
+        ws = torch.zeros(int(lib.tpg_build_grid_workspace_bytes(C.byref(p0))), dtype=torch.uint8, device=gpu)
+        def build(p, Hx=H):
+            rows = p.jend - p.jstart + 1 + 2 * H
+            out = [torch.full((rows, Nx + 2 * Hx), float("nan"), dtype=tdt, device=gpu) for _ in L.ARRAY_NAMES]
+            L.check(lib.tpg_build_grid(C.byref(p), L.ptr_table(out), ws.data_ptr(), ws.numel(), None))
+            torch.cuda.synchronize()
+            return out
+        for (j0, j1, Hx, fpl) in ((1, 60, 4, 70.0), (61, 120, 2, 75.0), (121, 180, 4, 70.0)):
+            want = build(params(j0, j1, 0, Hx, fpl), Hx)                    # fills the tables
+            got = build(params(j0, j1, 1, Hx, fpl), Hx)                     # reuses them
+            for name, a, b in zip(L.ARRAY_NAMES, got, want):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (name, j0, ft)
+        ws.fill_(0xFF)                                                       # NaN tables: the flag must not recompute them
+        bad = build(params(1, 60, 1))
+        assert bool(torch.isnan(bad[L.ARRAY_NAMES.index("lambda_cc")][H:-H, H:-H]).any())
+        good = build(params(1, 60, 0))
+        assert not bool(torch.isnan(good[L.ARRAY_NAMES.index("lambda_cc")][H:-H, H:-H]).any())
+    p = params(1, Ny, 2)
+    assert lib.tpg_build_grid(C.byref(p), L.ptr_table(good), ws.data_ptr(), ws.numel(), None) == -1 and b"unknown flag" in lib.tpg_last_error()

@@ -27,13 +27,15 @@ def timed(fn, reps=100, warm=60):
     return e0.elapsed_time(e1) / reps * 1e3            # us
 
 out = {"config": f"3600x1800x75 in {R} bands of {ny} rows, Float64, halo 4, fields c/u/v/zeta", "unit": "us"}
-for label, rank in (("north_band", R - 1), ("middle_band", R // 2)):
+for label, rank in (("north_band", R - 1), ("middle_band", R // 2), ("south_band", 0)):
     jstart, jend = 1 + ny * rank, ny * (rank + 1)
     p = _lib.TpgParams(NX, NY, NZ, H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F64, jstart, jend, 0)
     arrs = [torch.empty((ny + 2 * H, NX + 2 * H), dtype=torch.float64, device=dev) for _ in _lib.ARRAY_NAMES]
     ptrs = _lib.ptr_table(arrs)
     ws = torch.empty(int(lib.tpg_build_grid_workspace_bytes(C.byref(p))), dtype=torch.uint8, device=dev)
     out[label + "_build"] = timed(lambda: _lib.check(lib.tpg_build_grid(C.byref(p), ptrs, ws.data_ptr(), ws.numel(), st)))
+    pv = _lib.TpgParams(NX, NY, NZ, H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F64, jstart, jend, 1)     # TPG_BUILD_TABLES_VALID
+    out[label + "_build_tables_cached"] = timed(lambda: _lib.check(lib.tpg_build_grid(C.byref(pv), ptrs, ws.data_ptr(), ws.numel(), st)))
     fields = [torch.empty((NZ + 2 * H, ny + 2 * H, NX + 2 * H), dtype=torch.float64, device=dev) for _ in range(4)]
     for k, f in enumerate(fields):
         testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0xC4 + k, 12345.0, NX, ny, NZ, H, H, H, _lib.TPG_F64, None))
