@@ -496,6 +496,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    # the synthetic fields were written on the NULL stream; the side / comm streams are non-blocking streams and do not wait for it
+    torch.cuda.synchronize()
+
     # ---- N > 1: first contact with the neighbours under a deadline ---------------------------------------------------------
     if chain:
         dog.info.update(geometry=list(geom), seam_message_MB=4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8 / 1e6)
@@ -512,6 +515,50 @@ def main():
                 dog.set_phase(f"barrier after the first seam exchange ({form})")
                 dist.barrier()
             dog.disarm()
+        # ---- the seams just exchanged, checked bit for bit (both forms have run; a fill is idempotent on the rows that travel).  Every
+        # field is synthetic with a seed that names its band, so this rank can REBUILD what its neighbour owns: the neighbour's field,
+        # its local fill (periodic x; the zipper if it is the north band), and from it the interior rows the neighbour sent.  They
+        # must equal the halo rows this rank received -- all columns incl. the x halos, all levels incl. the z halos.  On the driver's
+        # multi-GPU run this is the first bit-exact check of the RCCL path between real ranks; a mismatch ends the job (all ranks
+        # agree first, so nobody is left in a barrier) with a diagnostic and no contract line.
+        dog.arm("seam verification after the first exchanges")
+        seam_check = {"sides": 0, "fields": n, "bit_exact": True, "bad": []}
+        if os.environ.get("TPG_BENCH_TEST_CORRUPT_SEAM") == str(rank):     # tests/test_gpu_bench_contract.py: the check must have teeth
+            fields[1][NZ // 2, (H - 1) if south_peer >= 0 else (ny + H), NX // 2] += 1.0
+        scratch = torch.empty(shape, dtype=torch.float64, device=dev)
+        for side, nb in (("south", band - 1), ("north", band + 1)):
+            if not (0 <= nb < bands):
+                continue
+            seam_check["sides"] += 1
+            owner = band if loopback else nb                          # loop-back: the "neighbour" on either side is this band itself
+            for fid, (name, fxl, fyl, fsg) in enumerate(SPECS):
+                testlib.check(tlib.tpg_fill_synthetic(scratch.data_ptr(), 0x5EED + fid + 16 * owner, 12345.0, NX, ny, NZ, H, H, H, _lib.TPG_F64, None))
+                one = _lib.ptr_table([scratch])
+                _lib.check(lib.tpg_fill_halo_regions(one, 1, (C.c_int8 * 1)(fxl), (C.c_int8 * 1)(fyl), (C.c_int32 * 1)(fsg), *geom,
+                                                     1 if owner == bands - 1 else 0, _lib.TPG_F64, None))
+                torch.cuda.synchronize()
+                # a neighbour sends the interior rows next to the shared seam.  Loop-back with ONE seam (an end band of the emulated
+                # chain): the rank's only send (its own rows next to that side) pairs with its only receive (the halo of that side)
+                one_seam_loop = loopback and (south_peer < 0 or north_peer < 0)
+                if side == "south":                                   # my halo rows j = 1-Hy..0  <-  its interior rows j = ny-Hy+1..ny
+                    got, want = fields[fid][:, :H], (scratch[:, H:2 * H] if one_seam_loop else scratch[:, ny:ny + H])
+                else:                                                 # my halo rows j = ny+1..ny+Hy  <-  its interior rows j = 1..Hy
+                    got, want = fields[fid][:, ny + H:], (scratch[:, ny:ny + H] if one_seam_loop else scratch[:, H:2 * H])
+                if not torch.equal(got, want):
+                    seam_check["bit_exact"] = False
+                    ne = (got != want).nonzero()
+                    seam_check["bad"].append({"side": side, "field": name, "cells": int(ne.shape[0]),
+                                              "first_level_row_col": ne[0].tolist(), "last_level_row_col": ne[-1].tolist()})
+        del scratch
+        agree = torch.tensor([1 if seam_check["bit_exact"] else 0], dtype=torch.int32, device=None if rehearse else dev)
+        if world > 1:
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if not seam_check["bit_exact"]:
+            print(json.dumps(dict(dog.info, event="seam_mismatch", **seam_check)), file=sys.stderr, flush=True)
+        if int(agree.item()) == 0:
+            dog.disarm()
+            os._exit(6)                                               # every rank leaves: the exchange delivered wrong halos somewhere
+        dog.disarm()
         # the rest of the run (warm-up, timed and instrumented steps: a few seconds) stays under a generous second deadline, so that
         # an exchange that stalls LATER also ends with a diagnostic instead of the driver's kill
         dog.seconds = max(10 * args.deadline, 600.0)
@@ -618,7 +665,7 @@ def main():
         t_fill_bracket, t_exchange, t_fillx = local_ms[uf], ex_ms[uf], local_ms[uf] + ex_ms[uf]
         # every band's own phase times travel to rank 0 for the line: at N = 8 the interior ranks carry two seams, the end ranks one,
         # and only the north rank folds
-        mine = {"rank": rank, "band": band, "rows": [jstart, jend], "build_ms": t_build, "local_fill_ms": t_fill_bracket,
+        mine = {"rank": rank, "band": band, "rows": [jstart, jend], "seams_bit_exact": seam_check["bit_exact"], "build_ms": t_build, "local_fill_ms": t_fill_bracket,
                 "exchange_ms": t_exchange, "exchange_ms_by_form": dict(ex_ms), "fill_plus_exchange_ms": t_fillx,
                 "seams": int(south_peer >= 0) + int(north_peer >= 0), "zipper": north_is_zipper}
         per_rank = [None] * world
@@ -691,6 +738,8 @@ def main():
                 "overlap_hidden_frac": hidden if overlap else 0.0,  # share of the shorter of (build, fill + exchange) that the step hides
                 "exchange_transport": transport_name + (" [loop-back: both peers are this rank, the transfers are device-local]" if loopback else ""),
                 "per_rank": per_rank,
+                "seam_check": "every rank rebuilt its neighbours' synthetic fields and compared the halo rows it received after the first exchanges "
+                              f"(monolithic and pipelined) bit for bit: {n} fields x (Nx + 2Hx) x Hy x (Nz + 2Hz) per seam side; all ranks passed",
                 "phase_timing": "build: one event pair around K back-to-back builds (main stream); local fill / exchange: hipEventRecord pairs on the "
                                 "side stream in a pass without the build; no marker sits on the build's stream inside a step",
                 "seam_message_bytes_per_direction": seam_bytes,

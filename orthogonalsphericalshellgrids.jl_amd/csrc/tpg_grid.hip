@@ -588,12 +588,11 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // Tile rows are dispatched in blockIdx.y order.  The NORTHERNMOST tile row goes first: on a band that holds row Ny its top wave
-    // takes the general (scalar, branchy) path through coord() -- fold, row-Ny substitution, poles -- and is several times slower than a
-    // fast-path wave; dispatched last it was a ~10 us tail of the whole launch (a 225-row north band built in 89 us against 77 us for
-    // a middle band, round 4), dispatched first it hides behind the other tiles.  The southernmost row (row 0 of a south band: the
-    // other general-path row) follows as blockIdx.y = 1.
-    const int ty = blockIdx.y == 0 ? (int)gridDim.y - 1 : (int)blockIdx.y - 1;
+    // Tile rows are dispatched in blockIdx.y order: NORTH to SOUTH.  The slow tiles of a launch are the northern ones -- around the two
+    // poles the cells have edges of tens of degrees and near-degenerate triangles, which the batch forms hand to their scalar fall-backs,
+    // and row Ny takes the general path through coord() -- so a band that holds them runs them first, behind everything else, instead of
+    // as the tail of the launch (round 4: a 225-row north band built in 89 us against 77 us for a middle band).
+    const int ty = (int)gridDim.y - 1 - (int)blockIdx.y;
     const int tx = blockIdx.x;
     const int s0 = g.jm_lo - 1 + ty * (R - 1);
     const int s = s0 + p;                                                    // this wave's step

@@ -111,6 +111,7 @@ def test_bench_two_ranks_rehearsal(gpu):
     pr = d["per_rank"]                                                # every rank's own phase times
     assert [r["rank"] for r in pr] == [0, 1] and pr[0]["rows"] == [1, 900] and pr[1]["rows"] == [901, 1800]
     assert [r["zipper"] for r in pr] == [False, True] and [r["seams"] for r in pr] == [1, 1] and all(r["build_ms"] > 0 for r in pr)
+    assert all(r["seams_bit_exact"] for r in pr)                      # each rank rebuilt its neighbour's field and compared the halo rows it received
     assert "cpu_baseline" not in d and "fill_step" not in d           # rank 0 at N = 1 only
     w = _two_rank_bench(["--scaling", "weak"], launcher="torchrun")
     assert w["scaling"] == "weak" and w["config"]["global_size"] == [3600, 3600, 75] and w["config"]["local_size"] == [3600, 1800, 75]
@@ -145,6 +146,23 @@ def test_bench_loopback_runs_the_rccl_branch(gpu, band):
     assert (d["roofline"]["launch_ms"] > 0) == (band == 7)                                               # only the zipper band launches the merged fold
     assert d["roofline_precompute"]["evaluated_cells"] == 3600 * (233 if band < 7 else 229)
     assert "cpu_baseline" not in d and "fill_step" not in d
+    # the seams were verified bit for bit against the neighbour's rebuilt field (here: this band's own) before anything was timed
+    assert pr[0]["seams_bit_exact"] is True and "bit for bit" in d["seam_check"]
+
+
+def test_bench_seam_check_has_teeth(gpu):
+    """One received halo cell altered after the first exchanges (TPG_BENCH_TEST_CORRUPT_SEAM): the seam verification must end the run
+    with exit status 6, a `seam_mismatch` diagnostic naming side and field on stderr, and no contract line."""
+    env = dict(os.environ, TPG_BENCH_TEST_CORRUPT_SEAM="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TPG_BENCH_REHEARSE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--loopback", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 6 and not p.stdout.strip(), (p.returncode, p.stdout[-500:], p.stderr[-2000:])
+    diag = [json.loads(l) for l in p.stderr.splitlines() if l.startswith("{") and "seam_mismatch" in l]
+    assert len(diag) == 1 and diag[0]["bit_exact"] is False and len(diag[0]["bad"]) == 1
+    bad = diag[0]["bad"][0]
+    assert (bad["side"], bad["field"], bad["cells"]) == ("south", "u", 1) and bad["first_level_row_col"] == [37, 3, 1800]
 
 
 def test_bench_deadline_fires_with_a_diagnostic(gpu):
