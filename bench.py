@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- TripolarGrid metric precompute + zipper halo fill at 1/10 deg x 75 levels on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak] [--exchange auto|monolithic|pipelined]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak] [--exchange auto|monolithic|pipelined_1|pipelined_2]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     (same thing, launcher supplied)
   python bench.py --loopback [--loopback-bands R] [--loopback-band r]                          (1 GPU: the RCCL branch on one rank)
 
@@ -23,7 +23,8 @@ For N > 1 the halo fill (local fill + seam exchange) runs on a side stream besid
 two touch disjoint memory.  Before the warm-up one fill runs under a host-side deadline: a stalled exchange ends the job
 with a one-line JSON diagnostic on stderr and a non-zero exit instead of a silent hang.  The seam exchange has two forms with
 identical results -- monolithic (pack all -> one RCCL group -> unpack all) and pipelined per field on a second stream
-(tpg_halo_exchange_y_pipelined) -- both are timed on every run (`exchange_ms_monolithic`, `exchange_ms_pipelined`, beside
+(tpg_halo_exchange_y_pipelined; in stages of 1 and of 2 fields) -- all are timed on every run (`exchange_ms_monolithic`,
+`exchange_ms_pipelined_1`, `exchange_ms_pipelined_2`, beside
 `link_floor_ms`); `--exchange auto` (default) runs the timed steps with whichever was faster (max over ranks).
 `--loopback` runs that whole N > 1 branch -- communicator bring-up under the watchdog, seam buffers, the one-call distributed
 fill in both forms, the side-stream overlap with the build, the instrumented passes -- on ONE GPU: a communicator of one rank
@@ -245,7 +246,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: strong = BASELINE config 4 (the 3600x1800x75 globe in N bands of 1800/N rows; default); weak = 1800 rows per rank")
-    ap.add_argument("--exchange", choices=("auto", "monolithic", "pipelined"), default="auto",
+    ap.add_argument("--exchange", choices=("auto", "monolithic", "pipelined_1", "pipelined_2"), default="auto",
                     help="N > 1: form of the RCCL seam exchange in the timed steps; auto = whichever the pre-pass measures faster (both are always reported)")
     ap.add_argument("--loopback", action="store_true",
                     help="1 GPU: run the N > 1 (RCCL) branch on a one-rank communicator whose peers are the rank itself")
@@ -422,8 +423,9 @@ def main():
     comm_stream = torch.cuda.Stream(dev, priority=prio) if (chain and comm is not None) else None
     comm_stream_ptr = C.c_void_p(comm_stream.cuda_stream) if comm_stream is not None else None
     overlap = chain and os.environ.get("TPG_BENCH_OVERLAP", "1") != "0"
-    FORMS = ("monolithic", "pipelined") if comm is not None else ("monolithic",)
-    FIELDS_PER_STAGE = 1
+    # exchange forms timed on every run: monolithic, and pipelined in stages of 1 and of 2 fields (4 and 2 stages of the 4 bench fields)
+    FORMS = ("monolithic", "pipelined_1", "pipelined_2") if comm is not None else ("monolithic",)
+    stage_of = lambda form: int(form.split("_")[1])
 
     def local_fill(kev=None):
         """fill_halo_regions! without the seams: zipper (north band) -> periodic x; kev = the first kernel's own start/stop events"""
@@ -437,9 +439,9 @@ def main():
         s_ = _lib.current_stream_ptr(dev)
         if comm is None:
             pending.begin().finish()
-        elif form == "pipelined":
+        elif form.startswith("pipelined"):
             _lib.check(lib.tpg_halo_exchange_y_pipelined_peers(comm.handle, south_peer, north_peer, fptrs, n, *seam_ptr, *geom, _lib.TPG_F64,
-                                                               s_, comm_stream_ptr, FIELDS_PER_STAGE))
+                                                               s_, comm_stream_ptr, stage_of(form)))
         else:
             _lib.check(lib.tpg_halo_exchange_y_peers(comm.handle, south_peer, north_peer, fptrs, n, *seam_ptr, *geom, _lib.TPG_F64, s_))
 
@@ -449,10 +451,10 @@ def main():
         if comm is None:
             local_fill()
             exchange_only()
-        elif form == "pipelined":
+        elif form.startswith("pipelined"):
             _lib.check(lib.tpg_fill_halo_regions_distributed_pipelined_peers(comm.handle, south_peer, north_peer, 1 if north_is_zipper else 0,
                                                                              fptrs, n, xl, yl, sg, *seam_ptr, *geom, _lib.TPG_F64,
-                                                                             s_, comm_stream_ptr, FIELDS_PER_STAGE))
+                                                                             s_, comm_stream_ptr, stage_of(form)))
         else:
             _lib.check(lib.tpg_fill_halo_regions_distributed_peers(comm.handle, south_peer, north_peer, 1 if north_is_zipper else 0,
                                                                    fptrs, n, xl, yl, sg, *seam_ptr, *geom, _lib.TPG_F64, s_))
@@ -730,8 +732,9 @@ def main():
                 "overlap": "halo fill (local fill + seam exchange) on a side stream, concurrent with the grid build" if overlap else None,
                 "exchange_ms": t_exchange,                          # the form the timed steps used; pack + send/recv + unpack, slowest rank
                 "exchange_form": used_form[0], "exchange_form_choice": args.exchange,
-                "exchange_ms_monolithic": ex_ms.get("monolithic"), "exchange_ms_pipelined": ex_ms.get("pipelined"),
-                "exchange_fields_per_stage": FIELDS_PER_STAGE if "pipelined" in FORMS else None,
+                "exchange_ms_monolithic": ex_ms.get("monolithic"),
+                "exchange_ms_pipelined": min((v for f, v in ex_ms.items() if f.startswith("pipelined")), default=None),   # the better of the two stage sizes
+                "exchange_ms_pipelined_1": ex_ms.get("pipelined_1"), "exchange_ms_pipelined_2": ex_ms.get("pipelined_2"),     # stages of 1 / 2 fields
                 "exchange_prepass_fill_ms": prepass,                # whole fill (local + exchange), back to back, per form: what `auto` chose on
                 "link_floor_ms": seam_bytes / 153.6e9 * 1e3,        # one seam direction over one xGMI link at its ~153.6 GB/s spec figure
                 "fill_plus_exchange_ms": t_fillx, "exchange_over_build": t_exchange / t_build,

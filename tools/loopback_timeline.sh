@@ -23,12 +23,16 @@ for f in sorted(glob.glob(out + "/ab_*.json")):
 files = glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True)
 rows = sorted(csv.DictReader(open(files[0])), key=lambda r: int(r["Start_Timestamp"]))
 # the timed steps: find the last 60 kernels before the instrumented passes; print a window of the trace relative to its first start
-names = [re.sub(r"\(.*", "", r["Kernel_Name"])[:40] for r in rows]
-idx = [i for i, n in enumerate(names) if "k_cells_tile" in n]
-i0 = idx[len(idx) // 2] - 6
+def short(n):
+    m = re.search(r"(k_[a-z_0-9]+|rccl\w+|nccl\w+)", n)
+    return m.group(1) if m else n[:40]
+names = [short(r["Kernel_Name"]) for r in rows]
+idx = [i for i, n in enumerate(names) if n == "k_cells_tile"]
+i0 = idx[len(idx) // 3] - 6
 t_ref = int(rows[i0]["Start_Timestamp"])
 with open(out + "/timeline.txt", "w") as fo:
     for r, n in zip(rows[i0:i0 + 40], names[i0:i0 + 40]):
-        line = "%9.2f %9.2f  q%-3s %s" % ((int(r["Start_Timestamp"]) - t_ref) / 1e3, (int(r["End_Timestamp"]) - t_ref) / 1e3, r.get("Queue_Id", "?"), n)
+        line = "%9.2f %9.2f %8.2f  q%-3s %s" % ((int(r["Start_Timestamp"]) - t_ref) / 1e3, (int(r["End_Timestamp"]) - t_ref) / 1e3,
+                                              (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", "?"), n)
         print(line); fo.write(line + "\n")
 PY
