@@ -318,3 +318,41 @@ def test_halo_fill_plan_marshals_the_one_call_distributed_fill(osg, gpu, monkeyp
     calls.clear()
     osg.halo_fill_plan([osg.CenterField(grid)], pack_free=True)()
     assert calls[0]["bufs"] == (None, None, None, None)
+
+
+def test_halo_fill_plan_marshals_the_pipelined_distributed_fill(osg, gpu, monkeypatch):
+    """fields_per_stage = k on a plan whose architecture carries an RcclComm: ONE call of tpg_fill_halo_regions_distributed_pipelined per
+    batch, with the plan's own second stream and the stage size AFTER the caller's stream (the recorder checks order and kinds and runs
+    the local fill; the C function itself runs against a real communicator in tools/rccl_selftest.py and bench.py --loopback);
+    pack_free + pipelined is refused."""
+    import ctypes as C
+    from orthogonalsphericalshellgrids.jl_amd.distributed import RcclComm
+    lib = osg._lib.lib()
+    size, halo, R = (32, 24, 2), (4, 4, 1), 3
+    calls = []
+
+    def recorder(comm, rank, nranks, fields, nfields, xl, yl, sg, ss, sn, rs, rn, Nx, Ny, Nz, Hx, Hy, Hz, ft, stream, comm_stream, fps):
+        calls.append(dict(rank=rank, nranks=nranks, nfields=nfields, bufs=(ss, sn, rs, rn), stream=stream, comm_stream=comm_stream, fps=fps))
+        return lib.tpg_fill_halo_regions(fields, nfields, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, 1 if rank == nranks - 1 else 0, ft, stream)
+
+    monkeypatch.setattr(lib, "tpg_fill_halo_regions_distributed_pipelined", recorder, raising=True)
+    monkeypatch.setattr(lib, "tpg_fill_halo_regions_distributed", lambda *a: pytest.fail("monolithic entry point called by a pipelined plan"), raising=True)
+    comm = RcclComm(C.c_void_p(0xC0FFEE), 1, R)
+    arch = osg.Distributed(osg.GPU(0), osg.Partition(y=R), local_rank=1, rccl_comm=comm)
+    grid = osg.TripolarGrid(arch, torch.float64, size=size, halo=halo)
+    fs = [osg.CenterField(grid), osg.XFaceField(grid), osg.YFaceField(grid)]
+    plan = osg.halo_fill_plan(fs, fields_per_stage=2)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        plan()
+        plan()
+    torch.cuda.synchronize()
+    assert len(calls) == 2 and all(c["fps"] == 2 and c["nfields"] == 3 and (c["rank"], c["nranks"]) == (1, R) for c in calls)
+    assert all(c["stream"].value == side.cuda_stream for c in calls)                       # the caller's current stream ...
+    cs = {c["comm_stream"].value for c in calls}
+    assert len(cs) == 1 and cs != {side.cuda_stream} and None not in cs                    # ... and ONE second stream, owned by the plan
+    assert all(b is not None for b in calls[0]["bufs"])                                    # a middle band: all four message buffers
+    with pytest.raises(ValueError):
+        osg.halo_fill_plan(fs, fields_per_stage=1, pack_free=True)
+    with pytest.raises(ValueError):
+        osg.halo_fill_plan(fs, fields_per_stage=-1)
