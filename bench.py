@@ -803,9 +803,15 @@ def main():
         if world > 1:
             dist.barrier()
         dog.disarm()
+        # every rank is past the last collective and the line is out: a communicator that will not shut down must not turn the run
+        # into a failure (or keep the launcher waiting) -- leave with status 0 after 30 s whatever the teardown is doing
+        t_exit = threading.Timer(30.0, lambda: os._exit(0))
+        t_exit.daemon = True
+        t_exit.start()
         if comm is not None:
             comm.destroy()
         dist.destroy_process_group()
+        t_exit.cancel()
 
 
 def load_traffic():
