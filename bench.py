@@ -263,8 +263,9 @@ def main():
         raise SystemExit("--loopback is a one-GPU mode (--gpus 1)")
     if args.loopback and not (0 <= args.loopback_band < args.loopback_bands and args.loopback_bands >= 2):
         raise SystemExit("--loopback-band must lie in 0 .. --loopback-bands - 1 (bands >= 2)")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher: become one.  Checked BEFORE torch is imported or a device is touched.
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1") or "1") == 1:
+        # no launcher (WORLD_SIZE unset, or a single-process environment that exports WORLD_SIZE=1): become one.  Checked BEFORE torch is
+        # imported or a device is touched.
         if args.scaling == "strong" and NY % args.gpus:
             raise SystemExit(f"--scaling strong needs {NY} % N == 0 (N = {args.gpus}); use N in 1,2,3,4,5,6,8,... or --scaling weak")
         sys.exit(launch_workers(args, sys.argv[1:]))
