@@ -588,10 +588,9 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // Tile rows are dispatched in blockIdx.y order: NORTH to SOUTH.  The slow tiles of a launch are the northern ones -- around the two
-    // poles the cells have edges of tens of degrees and near-degenerate triangles, which the batch forms hand to their scalar fall-backs,
-    // and row Ny takes the general path through coord() -- so a band that holds them runs them first, behind everything else, instead of
-    // as the tail of the launch (round 4: a 225-row north band built in 89 us against 77 us for a middle band).
+    // Tile rows are dispatched in blockIdx.y order: NORTH to SOUTH, so that the one slow row of a launch -- row Ny, whose wave takes the
+    // general (scalar) path through coord(): +2.2 us of block latency -- starts first instead of ending the launch.  Worth ~0.3 % at
+    // 1/10 degree (in-process A/B, round 4: 505.7 -> 504.2 us per build, i.e. inside the noise); kept because it costs nothing.
     const int ty = (int)gridDim.y - 1 - (int)blockIdx.y;
     const int tx = blockIdx.x;
     const int s0 = g.jm_lo - 1 + ty * (R - 1);

@@ -16,8 +16,11 @@ if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
             builds.append(cur); cur = []
         cur.append(r)
     builds.append(cur)
-    per = len(builds) // 3
-    for label, bs in (("north", builds[:per]), ("middle", builds[per:2 * per]), ("south", builds[2 * per:])):
+    # the launch sequence below: south, middle, north, then north, middle, south again -- whatever runs FIRST sits in the power-management
+    # transient that follows the onset of this FP64-heavy kernel, so every band is measured early and late
+    per = len(builds) // 6
+    for k, label in enumerate(("south (1st)", "middle (2nd)", "north (3rd)", "north (4th)", "middle (5th)", "south (6th)")):
+        bs = builds[k * per:(k + 1) * per]
         bs = bs[10:]                                        # warm-up
         names = [re.search(r"(k_[a-z_]+)", r["Kernel_Name"]).group(1) for r in bs[0]]
         durs = {n: statistics.median((int(b[i]["End_Timestamp"]) - int(b[i]["Start_Timestamp"])) / 1e3 for b in bs) for i, n in enumerate(names)}
@@ -33,7 +36,7 @@ NX, NY, NZ, H, R = 3600, 1800, 75, 4, 8
 ny = NY // R
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 lib = _lib.lib()
-for rank in (R - 1, R // 2, 0):
+for rank in (0, R // 2, R - 1, R - 1, R // 2, 0):
     jstart, jend = 1 + ny * rank, ny * (rank + 1)
     p = _lib.TpgParams(NX, NY, NZ, H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F64, jstart, jend, 0)
     arrs = [torch.empty((ny + 2 * H, NX + 2 * H), dtype=torch.float64, device=dev) for _ in _lib.ARRAY_NAMES]
