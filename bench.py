@@ -648,6 +648,17 @@ def main():
         b1.record()
         sync()
         t_build = b0.elapsed_time(b1) / args.steps
+        # the same past the power-management transient that follows the onset of the FP64-heavy cell kernel (~25 ms of sustained
+        # load; with few steps everything above sits inside it): 300 more builds untimed, then 100 timed
+        for _ in range(300):
+            build()
+        b0, b1 = ev(), ev()
+        b0.record()
+        for _ in range(100):
+            build()
+        b1.record()
+        sync()
+        t_build_steady = b0.elapsed_time(b1) / 100
         t_fill_kernel, local_ms = 0.0, {}
         for form in FORMS:
             marks = [[ev() for _ in range(3)] for _ in range(args.steps)]
@@ -668,7 +679,8 @@ def main():
         t_fill_bracket, t_exchange, t_fillx = local_ms[uf], ex_ms[uf], local_ms[uf] + ex_ms[uf]
         # every band's own phase times travel to rank 0 for the line: at N = 8 the interior ranks carry two seams, the end ranks one,
         # and only the north rank folds
-        mine = {"rank": rank, "band": band, "rows": [jstart, jend], "seams_bit_exact": seam_check["bit_exact"], "build_ms": t_build, "local_fill_ms": t_fill_bracket,
+        mine = {"rank": rank, "band": band, "rows": [jstart, jend], "seams_bit_exact": seam_check["bit_exact"], "build_ms": t_build,
+                "build_steady_ms": t_build_steady, "local_fill_ms": t_fill_bracket,
                 "exchange_ms": t_exchange, "exchange_ms_by_form": dict(ex_ms), "fill_plus_exchange_ms": t_fillx,
                 "seams": int(south_peer >= 0) + int(north_peer >= 0), "zipper": north_is_zipper}
         per_rank = [None] * world
@@ -677,6 +689,7 @@ def main():
         else:
             per_rank = [mine]
         t_build, t_exchange, t_fillx = reduce_max(t_build), reduce_max(t_exchange), reduce_max(t_fillx)
+        t_build_steady = reduce_max(t_build_steady)
         ex_ms = {f: reduce_max(v) for f, v in ex_ms.items()}
         t_fill_kernel = reduce_max(t_fill_kernel)                                    # only the zipper band has one
 
@@ -738,6 +751,9 @@ def main():
                 "exchange_ms_pipelined_1": ex_ms.get("pipelined_1"), "exchange_ms_pipelined_2": ex_ms.get("pipelined_2"),     # stages of 1 / 2 fields
                 "exchange_prepass_fill_ms": prepass,                # whole fill (local + exchange), back to back, per form: what `auto` chose on
                 "link_floor_ms": seam_bytes / 153.6e9 * 1e3,        # one seam direction over one xGMI link at its ~153.6 GB/s spec figure
+                # the band build past the cell kernel's power-management transient (300 untimed + 100 timed builds, slowest rank); `precompute_ms`
+                # is K builds right after the timed steps, which with few steps still sit inside it
+                "precompute_steady_ms": t_build_steady, "precompute_steady_cells_per_s": cells / (t_build_steady * 1e-3),
                 "fill_plus_exchange_ms": t_fillx, "exchange_over_build": t_exchange / t_build,
                 "overlap_hidden_frac": hidden if overlap else 0.0,  # share of the shorter of (build, fill + exchange) that the step hides
                 "exchange_transport": transport_name + (" [loop-back: both peers are this rank, the transfers are device-local]" if loopback else ""),

@@ -105,6 +105,7 @@ def test_bench_two_ranks_rehearsal(gpu):
     assert d["exchange_over_build"] > 0 and d["fill_plus_exchange_ms"] >= d["exchange_ms"]
     assert abs(d["value"] - 3600 * 1800 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]            # the globe is fixed: strong
     assert d["precompute_cells_per_s"] > 0 and d["roofline"]["launch_ms"] > 0
+    assert d["precompute_steady_ms"] > 0 and abs(d["precompute_steady_cells_per_s"] - 3600 * 1800 / (d["precompute_steady_ms"] * 1e-3)) < 1e-3 * d["precompute_steady_cells_per_s"]
     rp = d["roofline_precompute"]
     assert rp["bound"] == "fp64_valu" and rp["unit"] == "TFLOP/s" and abs(rp["frac"] - rp["achieved"] / rp["peak"]) < 1e-12
     assert rp["evaluated_cells"] == 3600 * 904 and rp["stored_cells"] == 3608 * 908                   # a 900-row band + one seam's halo rows
