@@ -636,7 +636,8 @@ def main():
         sync()
         avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)      # ms
         t_build, t_fill_bracket, t_exchange, t_fillx = avg(0, 1), avg(1, 2), None, None
-        t_fill_kernel = sum(elapsed_ms(e0, e1) for e0, e1 in kevs) / len(kevs)          # the merged kernel's own duration, timed steps
+        fill_live = [elapsed_ms(e0, e1) for e0, e1 in kevs]
+        t_fill_kernel = sum(fill_live) / len(fill_live)                                 # the merged kernel's own duration, timed steps
         for e0, e1 in kevs:
             lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
     else:
@@ -702,7 +703,8 @@ def main():
             _lib.check(lib.tpg_zipper_fill_timed(fptrs, n, xl, yl, sg, *geom, 1, NZ, _lib.TPG_F64, stream, fevs[k][0], fevs[k][1]))
             _lib.check(lib.tpg_periodic_x_fill(fptrs, n, *geom, _lib.TPG_F64, stream))
         torch.cuda.synchronize()
-        fold = sum(elapsed_ms(e0, e1) for e0, e1 in fevs) / len(fevs)
+        fold_live = [elapsed_ms(e0, e1) for e0, e1 in fevs]
+        fold = sum(fold_live) / len(fold_live)
         for e0, e1 in fevs:
             lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
 
@@ -780,6 +782,7 @@ def main():
                 "frac": fill_bytes / (t_fill_kernel * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": tm,
                 "algorithmic_bytes_per_launch": fill_bytes, "algorithmic_bytes_fold": zbytes, "algorithmic_bytes_periodic_x": pbytes,
                 "launch_ms": t_fill_kernel, "measured": "the kernel's own start/stop events on every timed step (hipExtLaunchKernelGGL)",
+                "launch_ms_median_min_max": [statistics.median(fill_live), min(fill_live), max(fill_live)],
                 "traffic_frac": (tm / (t_fill_kernel * 1e-3) / 1e9 / HBM_PEAK_GBPS) if tm else None,
                 "note": "the periodic-x part moves 128 B per row but must fetch and dirty 3 whole 128-B lines per row pair (row pitch 225.5 lines): "
                         "counter traffic is ~1.5x algorithmic and the launch sits at the device's line rate (DESIGN.md 6)"}
@@ -789,6 +792,9 @@ def main():
                 "achieved": zbytes / (fold * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": zbytes / (fold * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": tz,
                 "algorithmic_bytes_per_launch": zbytes, "launch_ms": fold,
+                # the mean is the figure of record; median / min / max show whether a few event pairs are off (seen on one box: mean 19.1 us
+                # live against 14.4 us for the same launches in a rocprofv3 trace)
+                "launch_ms_median_min_max": [statistics.median(fold_live), min(fold_live), max(fold_live)],
                 "measured": f"the kernel's own start/stop events over {args.steps} launches in step context (build -> fold -> periodic x), after the timed steps"}
             if aux:
                 line["roofline_fold"]["copy_ceiling_ms"] = aux["zipper_copy_ceiling_ms"]
