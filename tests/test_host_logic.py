@@ -204,3 +204,34 @@ def test_convert_to_0_360(osg):
     """src/OrthogonalSphericalShellGrids.jl:24 with Julia's truncated `%`"""
     f = osg.convert_to_0_360
     assert f(0.0) == 0.0 and f(360.0) == 0.0 and f(-90.0) == 270.0 and f(725.5) == 5.5 and f(-725.5) == 354.5 and f(359.9999) == 359.9999
+
+
+def test_traffic_json_is_keyed_per_kernel_source():
+    """profiles/traffic.json: every kernel entry names the files its kernel is compiled from and one hash over them; bench.py reports a
+    kernel's PMC traffic only while that hash matches the tree (the file used to be keyed to the zipper header only, so a
+    changed cell kernel kept a stale figure).  A stale entry is dropped, never reported."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    tj = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert "kernel_source_sha16" not in tj                                   # the single global key is gone
+    ks = tj["kernels"]
+    for name in ("k_fill_merged", "k_zipper_cols", "k_periodic_x_vec", "k_cells_tile", "k_tables", "k_halos"):
+        e = ks[name]
+        assert e["sources"] and all(os.path.exists(os.path.join(root, s)) for s in e["sources"]) and len(e["sources_sha16"]) == 16
+        assert e["hbm_bytes_per_launch"] == 2 * e["fetch_bytes_raw"] + e["write_bytes"]      # gfx950: FETCH_SIZE counts 128-B requests as 64 B
+    assert any("tpg_grid.hip" in s for s in ks["k_cells_tile"]["sources"]) and any("tpg_zipper_kernels.hpp" in s for s in ks["k_fill_merged"]["sources"])
+    live = bench.load_traffic()
+    for name, e in ks.items():                                                # reported <=> the hash over its sources still matches
+        assert (name in live) == (bench.sources_sha16(e["sources"]) == e["sources_sha16"])
+    # a changed source drops exactly the kernels compiled from it
+    saved = bench.sources_sha16
+    try:
+        bench.sources_sha16 = lambda srcs: "0" * 16 if any("tpg_grid.hip" in s for s in srcs) else saved(srcs)
+        stale = bench.load_traffic()
+        assert "k_cells_tile" not in stale and "k_tables" not in stale and ("k_fill_merged" in stale) == ("k_fill_merged" in live)
+    finally:
+        bench.sources_sha16 = saved
