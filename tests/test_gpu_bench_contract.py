@@ -56,6 +56,7 @@ def test_bench_prints_one_contract_line(gpu):
     assert f32["fold_algorithmic_bytes"] == zb // 2 and 0 < f32["fold_ms"] < d["zipper_cold_ms"] * 1.2
     assert f32["fill_algorithmic_bytes"] == (zb + pb) // 2 and f32["build_cells_per_s"] > 1e9
     assert "prewarm_steps" not in d                  # exactly W warm-up steps
+    assert d["aux_order"].startswith("geometry, builds")   # which auxiliary measurement precedes the warm-up is part of the line
     assert "exchange_ms" not in d and "periodic_x" not in d and "line_frac_of_hbm_peak" not in json.dumps(d)
     # config 5: the fills of one baroclinic step at 1/24 degree x 100 levels
     fs = d["fill_step"]
