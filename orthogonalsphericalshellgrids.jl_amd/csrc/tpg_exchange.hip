@@ -254,19 +254,27 @@ int tpg_halo_exchange_y_pipelined_peers(void* comm, int south_peer, int north_pe
     const size_t per_field = tpg_y_halo_buffer_elems(1, Nx, Nz, Hx, Hy, Hz);
     auto slice = [&](void* base, int f0) -> void* { return base ? static_cast<char*>(base) + (size_t)f0 * per_field * esz : nullptr; };
 
-    // ordering events: a thread-local pool (timing disabled), grown on demand and kept for the life of the thread -- creating and
-    // destroying 2 x stages events per fill cost more host time than the RCCL groups themselves.  Re-recording an event does not
-    // disturb a wait enqueued on it earlier (the wait took the state it had then).
+    // ordering events: a thread-local pool (timing disabled) PER DEVICE -- an event may only be recorded on a stream of the device it was
+    // created on, and one host thread may drive several devices -- created at a thread's first pipelined exchange on that device and kept
+    // for the life of the thread (creating and destroying 2 x stages events per fill cost more host time than the RCCL groups themselves).
+    // Re-recording an event does not disturb a wait enqueued on it earlier (the wait took the state it had then).
     hipEvent_t *packed_ev = nullptr, *moved_ev = nullptr;
     if (two) {
-        static thread_local hipEvent_t pool[2 * TPG_MAX_FIELDS];
-        static thread_local int pooled = 0;
-        while (pooled < 2 * TPG_MAX_FIELDS) {                  // once per thread
-            const hipError_t ee = hipEventCreateWithFlags(&pool[pooled], hipEventDisableTiming);
+        constexpr int kMaxDevices = 64;
+        struct Pool { hipEvent_t ev[2 * TPG_MAX_FIELDS]; int n; };
+        static thread_local Pool* pools[kMaxDevices] = {};
+        int device = 0;
+        hipError_t de = hipGetDevice(&device);
+        if (de != hipSuccess) return tpg::hip_status(de, "hipGetDevice");
+        if (device < 0 || device >= kMaxDevices) { tpg::set_error("device ordinal %d outside the event pool", device); return TPG_ERR_UNSUPPORTED; }
+        if (!pools[device]) pools[device] = new Pool{ {}, 0 };          // one small record per (thread, device), never freed
+        Pool& pool = *pools[device];
+        while (pool.n < 2 * TPG_MAX_FIELDS) {                            // once per thread and device
+            const hipError_t ee = hipEventCreateWithFlags(&pool.ev[pool.n], hipEventDisableTiming);
             if (ee != hipSuccess) return tpg::hip_status(ee, "hipEventCreateWithFlags");
-            ++pooled;
+            ++pool.n;
         }
-        packed_ev = pool; moved_ev = pool + TPG_MAX_FIELDS;
+        packed_ev = pool.ev; moved_ev = pool.ev + TPG_MAX_FIELDS;
     }
     auto destroy_events = []() {};
 #define TPG_PIPE_CHECK(expr) do { if ((rc = (expr))) { destroy_events(); return rc; } } while (0)
