@@ -229,7 +229,7 @@ int tpg_halo_exchange_y_peers(void *comm, int south_peer, int north_peer, void *
  * form delivers (same pack / unpack kernels on slices).  On return `stream` is ordered after every transfer and unpack, and
  * comm_stream holds no work `stream` does not wait for.  comm_stream: a second hipStream_t of the caller on the same device
  * (NULL or == stream: the same stages on one stream, no overlap).  All four message buffers are required for every side
- * with a peer (no pack-free form).  The ordering events come from a thread-local pool (created at a thread's first call). */
+ * with a peer (no pack-free form).  The ordering events come from a pool kept per host thread and device (created at the first call). */
 int tpg_halo_exchange_y_pipelined(void *comm, int rank, int nranks, void *const fields[], int nfields,
                                   void *send_south, void *send_north, void *recv_south, void *recv_north,
                                   int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
