@@ -90,6 +90,20 @@ int main(void)
                    (unsigned long)diff, tpg_comm_available() == TPG_OK ? "bound" : "absent");
             free(h2);
         }
+        /* ... and through its pipelined form (tpg_fill_halo_regions_distributed_pipelined: the seam exchange in stages of k fields on a
+           second stream).  A one-band chain has no seam, so no communicator, buffers or second stream are needed: it is the serial fill
+           again, and the pole point flips back */
+        TPGCHECK(tpg_fill_halo_regions_distributed_pipelined(NULL, 0, 1, fields, 1, xloc, yloc, sign, NULL, NULL, NULL, NULL,
+                                                             Nx, Ny, Nz, H, H, H, TPG_F64, NULL, NULL, 1));
+        HIPCHECK(hipDeviceSynchronize());
+        {
+            double *h3 = (double *)malloc(n3 * sizeof(double));
+            size_t q3, diff3 = 0;
+            HIPCHECK(hipMemcpy(h3, u, n3 * sizeof(double), hipMemcpyDeviceToHost));
+            for (q3 = 0; q3 < n3; ++q3) diff3 += (h3[q3] != h[q3]);
+            printf("pipelined entry point, one band: %lu cells differ from the serial fill\n", (unsigned long)diff3);
+            free(h3);
+        }
         /* an argument error comes back as a status + message, never as an exception across the boundary */
         printf("odd Nlambda -> status %d: %s\n",
                tpg_fill_halo_regions(fields, 1, xloc, yloc, sign, 11, Ny, Nz, H, H, H, 1, TPG_F64, NULL), tpg_last_error());

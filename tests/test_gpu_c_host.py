@@ -44,5 +44,7 @@ def test_c_host_reproduces_the_reference_known_answers(gpu, kats, tmp_path):
     assert mid == -1.0
     assert "status -2" in out and "even" in out
     # the distributed entry point on a one-band chain is the serial fill: only the self-mapped pole point (sign -1) changes again
-    m = re.search(r"one band: (\d+) cells differ", out)
+    m = re.search(r"distributed entry point, one band: (\d+) cells differ", out)
     assert m and int(m.group(1)) == 1, out
+    m = re.search(r"pipelined entry point, one band: (\d+) cells differ", out)      # a third fill: the pole point is back where the first fill left it
+    assert m and int(m.group(1)) == 0, out
