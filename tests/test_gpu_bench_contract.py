@@ -64,14 +64,14 @@ def test_bench_prints_one_contract_line(gpu):
                                and abs(fs["total_us"] - fs["fill3d_us"] - fs["substep_fills_us"]) < 1e-6 and fs["fields_GB"] > 160)
 
 
-def _two_rank_bench(extra, launcher="self"):
+def _two_rank_bench(extra, launcher="self", ranks=2):
     """two ranks on this one GPU (TPG_BENCH_REHEARSE=1: gloo, host-staged seams).  launcher "self": `python bench.py --gpus 2`, no
     launcher on the command line -- bench.py starts its own workers (what the driver's N = 1 command form becomes at N > 1);
     "torchrun": the documented `python -m torch.distributed.run ...` form."""
     env = dict(os.environ, TPG_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1"] + extra
     if launcher == "self":
         cmd = [sys.executable] + tail
     else:
@@ -79,7 +79,7 @@ def _two_rank_bench(extra, launcher="self"):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + tail
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -118,6 +118,18 @@ def test_bench_two_ranks_rehearsal(gpu):
     w = _two_rank_bench(["--scaling", "weak"], launcher="torchrun")
     assert w["scaling"] == "weak" and w["config"]["global_size"] == [3600, 3600, 75] and w["config"]["local_size"] == [3600, 1800, 75]
     assert abs(w["value"] - 2 * 3600 * 1800 / (w["ms_per_step"] * 1e-3)) <= 1e-6 * w["value"]
+
+
+def test_bench_four_ranks_rehearsal_interior_ranks_verify_both_seams(gpu):
+    """`python bench.py --gpus 4` (self-started workers, gloo rehearsal on this one GPU): the two interior ranks carry two seams each, with
+    different neighbours on either side, and every rank's bit-exact seam verification must pass (each rebuilds BOTH neighbours' rows)."""
+    d = _two_rank_bench([], ranks=4)
+    assert d["n_gpus"] == 4 and d["config"]["rows_per_rank"] == 450 and d["config"]["parallelism"] == "latitude-bands x4"
+    pr = d["per_rank"]
+    assert [r["rows"] for r in pr] == [[1, 450], [451, 900], [901, 1350], [1351, 1800]]
+    assert [r["seams"] for r in pr] == [1, 2, 2, 1] and [r["zipper"] for r in pr] == [False, False, False, True]
+    assert all(r["seams_bit_exact"] for r in pr) and "bit for bit" in d["seam_check"]
+    assert abs(d["value"] - 3600 * 1800 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 
 @pytest.mark.parametrize("band", [3, 7])
