@@ -32,9 +32,13 @@ whose south / north peer is the rank itself, for band r of a chain of R (default
 config 4 with two seams; band R-1 = the zipper band).  Its seam "transfers" are device-local copies by RCCL's own kernels: a
 rehearsal of the code path, not a scaling measurement, and the line says so.
 
-Exactly W untimed warm-up steps, then exactly K timed steps.  The auxiliary measurements the line also carries (fold-only
-launches by cache state, the same-shape copy ceiling, Float32 figures, config 2, config 5) run BEFORE the warm-up; the
-fold-only pass behind `roofline_fold` and the per-phase breakdown run AFTER the timed steps.  None of them is a step.
+Order of a run: set-up -> [N > 1: first seam exchange under a deadline, bit-exact seam check, exchange pre-pass] -> the DECLARED
+clock pre-roll (`clock_preroll`: P plain tpg_build_grid calls, ~35 ms, so that a short run starts from the sustained FP64 clock
+state; `--preroll 0` = none) -> exactly W untimed warm-up steps -> exactly K timed steps (`value`, `ms_per_step`) -> untimed
+instrumented passes (per-phase breakdown, the fold-only pass behind `roofline_fold`) -> K steps started right after >= 50 ms of
+HBM-bound work, no pre-roll, no warm-up (`ms_per_step_cold_onset`: what a caller's FIRST builds cost) -> the auxiliary
+measurements (fold / fill by cache state, copy ceiling, the 8- and 16-field batched fold, Float32, config 2, geometry, config 5)
+-> cpu_baseline.  Nothing optional precedes the timed region: `value` is the same with --no-aux / --no-fill-step.
 
 value = horizontal grid cells of all ranks / step time (max over ranks).  `roofline` is the halo-fill kernel the step launches
 (k_fill_merged: the zipper halo fill as the product issues it, HBM-bound); `roofline_fold` is the fold alone (k_zipper_cols, the
@@ -173,6 +177,71 @@ class Watchdog:
         self.phase = "idle"
 
 
+def chain_layout(world, rank, scaling="strong", loopback=None):
+    """The latitude-band chain as every worker derives it from (WORLD_SIZE, RANK) alone -- no device, no torch: one band per process
+    (src/distributed_tripolar_grid.jl:36-49: Partition(y = R), rank 0 southernmost; :75,143-147: the last rank owns the zipper) or,
+    `loopback = (R, r)`, band r of an emulated chain of R on one process whose peers are the rank itself.  Returns the band count, this
+    band, rows per rank and the global row range, the global size, the RCCL peers (-1 = no seam on that side) and who zips."""
+    bands, band = loopback if loopback else (world, rank)
+    chain = bands > 1
+    strong = chain and scaling == "strong"
+    if strong and NY % bands:
+        # the remainder rule of Oceananigans' local_size for Ny % R != 0 is unpinned (DESIGN.md 2): config 4 divides evenly
+        raise SystemExit(f"--scaling strong needs {NY} % N == 0 (N = {bands}); use N in 1,2,3,4,5,6,8,... or --scaling weak")
+    ny = NY // bands if strong else NY
+    gsize = (NX, NY, NZ) if (strong or not chain) else (NX, NY * bands, NZ)
+    if loopback:
+        south_peer, north_peer = (0 if band > 0 else -1), (0 if band < bands - 1 else -1)
+    else:
+        south_peer, north_peer = (rank - 1 if rank > 0 else -1), (rank + 1 if rank < world - 1 else -1)
+    return {"bands": bands, "band": band, "chain": chain, "strong": strong, "ny": ny, "gsize": gsize,
+            "jstart": band * ny + 1, "jend": band * ny + ny, "south_peer": south_peer, "north_peer": north_peer,
+            "north_is_zipper": band == bands - 1, "seams": int(south_peer >= 0) + int(north_peer >= 0)}
+
+
+def plan_rehearsal(args, world, rank, contract_out):
+    """TPG_BENCH_REHEARSE=plan: the start-up of an N-rank run WITHOUT a device, for N the box's process guard does not allow on one
+    card (at most 6 processes may hold the GPU; BASELINE config 4 has 8).  Every worker runs what the real worker runs before its
+    first kernel -- launcher environment, gloo rendezvous on 127.0.0.1, chain_layout, osg.local_row_range on the Distributed
+    architecture, the seam plan -- then swaps seam-SHAPED host messages with its neighbours through the product's
+    torch_distributed_transport (message [field][level][Hy][Nx+2Hx] of tags naming sender band, side and field) and checks what
+    arrived, gathers every rank's record on rank 0 exactly as the real line's `per_rank` travels, and prints ONE line
+    {"event": "bench_plan", ...}: a plan, not a measurement -- it carries no metric, value or time."""
+    import torch
+    import torch.distributed as dist
+    import orthogonalsphericalshellgrids.jl_amd as osg
+    from orthogonalsphericalshellgrids.jl_amd.distributed import exchange_plan, SOUTH, NORTH
+    L = chain_layout(world, rank, args.scaling)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    arch = osg.Distributed(osg.CPU(), osg.Partition(y=L["bands"]), local_rank=L["band"])
+    jstart, jend = osg.local_row_range(L["gsize"][1], arch)
+    assert (jstart, jend) == (L["jstart"], L["jend"]) and jend - jstart + 1 == L["ny"], (jstart, jend, L)
+    plan = exchange_plan(L["band"], L["bands"])
+    n = len(SPECS)
+    shape = (n, NZ + 2 * H, H, NX + 2 * H)
+    tag = lambda b, side: (torch.arange(n, dtype=torch.float64).view(n, 1, 1, 1) + 16.0 * b + 4096.0 * side).expand(shape).contiguous()
+    send = {m.side: tag(L["band"], m.side) for m in plan}              # "band b's rows next to `side`"
+    recv = {m.side: torch.full(shape, -1.0, dtype=torch.float64) for m in plan}
+    osg.torch_distributed_transport(plan, send, recv, None)
+    ok = all(torch.equal(recv[m.side], tag(m.peer, NORTH if m.side == SOUTH else SOUTH)) for m in plan)
+    mine = {"rank": rank, "band": L["band"], "rows": [jstart, jend], "seams": L["seams"], "zipper": L["north_is_zipper"],
+            "peers": {"south": L["south_peer"], "north": L["north_peer"]}, "seam_tags_ok": ok,
+            "seam_message_bytes_per_direction": n * (NX + 2 * H) * H * (NZ + 2 * H) * 8}
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
+    dist.barrier()
+    if rank == 0:
+        per_band_hbm = (4 + 1) * (NZ + 2 * H) * (L["ny"] + 2 * H) * (NX + 2 * H) * 8 + 20 * (L["ny"] + 2 * H) * (NX + 2 * H) * 8
+        contract_out.write(json.dumps({"event": "bench_plan", "n_gpus": world, "scaling": args.scaling, "global_size": list(L["gsize"]),
+                                       "rows_per_rank": L["ny"], "per_rank": per_rank, "hbm_bytes_per_rank": per_band_hbm,
+                                       "note": "device-free rehearsal of an N-rank start-up (launcher, rendezvous, band layout, seam pairing "
+                                               "over gloo); no kernel ran, nothing was timed"}) + "\n")
+        contract_out.flush()
+    dist.destroy_process_group()
+    return 0 if ok else 8
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -204,7 +273,7 @@ def launch_workers(args, argv, script=None):
 
     def relay():
         for ln in procs[0].stdout:
-            if ln.lstrip().startswith('{"metric"'):
+            if ln.lstrip().startswith(('{"metric"', '{"event": "bench_plan"')):
                 relayed.append(ln)
                 sys.stdout.write(ln); sys.stdout.flush()
             else:
@@ -254,6 +323,8 @@ def main():
     ap.add_argument("--loopback-band", type=int, default=3, help="--loopback: which band of the chain this GPU plays (R-1 = the zipper band)")
     ap.add_argument("--deadline", type=float, default=float(os.environ.get("TPG_BENCH_DEADLINE_S", "120")),
                     help="seconds allowed for communicator bring-up and for the first seam exchange (N > 1)")
+    ap.add_argument("--preroll", type=int, default=-1,
+                    help="plain tpg_build_grid calls before the warm-up steps (the declared clock pre-roll); default 64 per 1800 rows of band, 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fill-step", action="store_true", help="skip the config-5 (1/24 deg x 100 levels) fill_step measurement")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary measurements (cache states, copy ceiling, Float32, config 2, geometry)")
@@ -295,26 +366,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if os.environ.get("TPG_BENCH_REHEARSE") == "plan" and world > 1 and not args.loopback:
+        sys.exit(plan_rehearsal(args, world, rank, contract_out))
     # the latitude-band chain: one band per process -- or, --loopback, band r of an emulated chain of R on this one process
     loopback = args.loopback
-    bands, band = (args.loopback_bands, args.loopback_band) if loopback else (world, rank)
-    chain = bands > 1
-    strong = chain and args.scaling == "strong"
-    if strong and NY % bands:
-        # the remainder rule of Oceananigans' local_size for Ny % R != 0 is unpinned: config 4 divides evenly
-        raise SystemExit(f"--scaling strong needs {NY} % N == 0 (N = {bands}); use N in 1,2,3,4,5,6,8,... or --scaling weak")
-    assert torch.cuda.is_available(), f"bench.py needs a HIP device (rank {rank} of {world})"
+    L = chain_layout(world, rank, args.scaling, (args.loopback_bands, args.loopback_band) if loopback else None)
+    bands, band, chain, strong = L["bands"], L["band"], L["chain"], L["strong"]
+    south_peer, north_peer, north_is_zipper = L["south_peer"], L["north_peer"], L["north_is_zipper"]   # RCCL peers; -1 = no seam on that side
     rehearse = os.environ.get("TPG_BENCH_REHEARSE") == "1" and not loopback
+    # A node that shows fewer devices than ranks (a short node, a narrowed HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES) must end the job with
+    # one readable line, not with N raw "invalid device ordinal" tracebacks.  device_count() does not initialise the GPU.
+    visible = int(os.environ["TPG_BENCH_TEST_DEVICE_COUNT"]) if "TPG_BENCH_TEST_DEVICE_COUNT" in os.environ else torch.cuda.device_count()
+    if not rehearse and visible < max(local_rank + 1, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        if rank == 0:
+            print(json.dumps({"event": "too_few_devices", "visible": visible, "requested": world, "rank": rank, "local_rank": local_rank,
+                              "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES"),
+                              "hint": "bench.py runs one process per GPU: --gpus N needs N visible HIP devices on this node "
+                                      "(a one-GPU rehearsal of the N-rank code path: TPG_BENCH_REHEARSE=1, N <= 6; its start-up only, any N: TPG_BENCH_REHEARSE=plan)"}), file=sys.stderr, flush=True)
+        sys.exit(7)
+    assert torch.cuda.is_available(), f"bench.py needs a HIP device (rank {rank} of {world})"
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # RCCL peers (ranks of the communicator); -1 = no seam on that side.  Loop-back: both peers are this rank
-    if loopback:
-        south_peer, north_peer = (0 if band > 0 else -1), (0 if band < bands - 1 else -1)
-    else:
-        south_peer, north_peer = (rank - 1 if rank > 0 else -1), (rank + 1 if rank < world - 1 else -1)
-    north_is_zipper = band == bands - 1
     peers = {"south": south_peer if south_peer >= 0 else None, "north": north_peer if north_peer >= 0 else None}
     dog = Watchdog(args.deadline, {"rank": rank, "world": world, "peers": peers, "device": local_rank})
     if loopback:
@@ -353,12 +427,11 @@ def main():
                 print(f"[bench rank {rank}] tpg_comm_init_rank unavailable ({comm_error}); seam exchange over torch.distributed", file=sys.stderr)
 
     lib, tlib = _lib.lib(), testlib.lib()
-    ny = NY // bands if strong else NY                             # rows of this rank's band
-    gsize = (NX, NY, NZ) if (strong or not chain) else (NX, NY * bands, NZ)
+    ny, gsize = L["ny"], L["gsize"]                                 # rows of this rank's band, size of the global grid
     if chain:
         arch = osg.Distributed(osg.GPU(0 if rehearse else local_rank), osg.Partition(y=bands), local_rank=band, rccl_comm=comm)
         jstart, jend = osg.local_row_range(gsize[1], arch)
-        assert jend - jstart + 1 == ny, (jstart, jend, ny)
+        assert (jstart, jend) == (L["jstart"], L["jend"]) and jend - jstart + 1 == ny, (jstart, jend, L)
     else:
         arch, jstart, jend = osg.GPU(local_rank), 1, NY
 
@@ -590,19 +663,26 @@ def main():
         else:
             used_form[0] = min(FORMS, key=lambda f: prepass[f])     # the same on every rank: prepass holds max-over-ranks values
 
-    # ---- auxiliary measurements (not steps) ----------------------------------------------------------------------------------
-    # Order: the config-5 block first (it allocates and frees 162 GB), the config-3 auxiliary block last.  The FP64-heavy cell kernel
-    # starts a power-management transient whenever it follows lighter work -- 535 us on its first launch, up to 690 us a few launches later,
-    # back to its steady 490 us only after ~40 launches (~25 ms; profiles/r03/cells_sequence_driver_args.txt).  Up to round 3 the auxiliary
-    # block ended with HBM-bound work and `--steps 20 --warmup 5` timed exactly that transient (0.63-0.65 ms per step); since round 4 it ends
-    # with its own FP64 build measurements (see `auxiliary`), so a short run starts from the sustained state (0.58 ms) like the defaults
-    # (50 + 200 steps: 0.55-0.56 ms).  DESIGN.md 6 quotes all of them; TPG_BENCH_AUX_ORDER=r3 restores the old order.
-    fill_step = None
-    if not chain and not args.no_fill_step:
-        fill_step = fill_step_config5(torch, osg, _lib, tlib, dev)
-    aux = {}
-    if not chain and not args.no_aux:
-        aux = auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, sg, geom, p, out, out_ptrs, ws, hip_event, elapsed_ms)
+    # ---- declared clock pre-roll (not steps) ---------------------------------------------------------------------------------
+    # The FP64-heavy cell kernel starts a power-management transient whenever it follows lighter work -- 535 us on its first launch, up
+    # to 690 us a few launches later, its steady 490 us only after ~25 ms of sustained FP64 load (profiles/r03/cells_sequence_driver_args.txt).
+    # A short run (`--steps 20 --warmup 5` = 14 ms) would time exactly that transient.  So the run declares what it does about it: P plain
+    # tpg_build_grid calls of this rank's band (default: ~35 ms of them) immediately before the W warm-up steps, reported as `clock_preroll`
+    # {builds, ms}; `--preroll 0` switches it off.  Nothing else precedes the warm-up: every auxiliary measurement runs AFTER the timed and
+    # instrumented passes, so `value` does not depend on --no-aux / --no-fill-step.  The figure a caller sees on a FIRST build after
+    # HBM-bound work is in the line as well: `ms_per_step_cold_onset` (below).
+    preroll_n = args.preroll if args.preroll >= 0 else 64 * (bands if strong else 1)
+    preroll = {"builds": preroll_n, "ms": 0.0, "what": "plain tpg_build_grid calls of the timed geometry, back to back, immediately before the warm-up "
+                                                       "steps: brings the clocks to the sustained FP64 state (not steps, not timed into `value`)"}
+    if preroll_n:
+        sync()
+        b0, b1 = ev(), ev()
+        b0.record()
+        for _ in range(preroll_n):
+            build()
+        b1.record()
+        torch.cuda.synchronize()
+        preroll["ms"] = b0.elapsed_time(b1)
 
     # ---- W warm-up steps, K timed steps ------------------------------------------------------------------------------------
     sync()
@@ -709,6 +789,35 @@ def main():
         for e0, e1 in fevs:
             lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
 
+    # ---- the step right after HBM-bound work: K steps, no pre-roll, no warm-up, after >= 50 ms of streaming traffic ------------------------
+    # (what the FIRST builds of a caller cost: the cell kernel's onset transient included.  Untimed region, N = 1 only.)
+    cold_onset = None
+    if not chain:
+        flush = torch.zeros(1 << 27, dtype=torch.float64, device=dev)          # 1 GiB
+        torch.cuda.synchronize()
+        h0, h1 = ev(), ev()
+        h0.record()
+        for _ in range(100):                                                    # 100 x (1 GiB read + 1 GiB write) ~ 60 ms
+            flush.add_(1.0)
+        h1.record()
+        torch.cuda.synchronize()
+        t0c = time.perf_counter()
+        for k in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        cold_onset = {"ms_per_step": (time.perf_counter() - t0c) / args.steps * 1e3, "steps": args.steps, "preceded_by_ms_of_hbm_bound_work": h0.elapsed_time(h1),
+                      "what": f"{args.steps} steps timed like the timed region, but started right after 100 in-place passes over 1 GiB instead of after the "
+                              "pre-roll and the warm-up: the cell kernel's power-management onset transient is inside"}
+        del flush
+
+    # ---- auxiliary measurements (not steps; after everything that is timed into the contract keys) -------------------------------------------
+    aux, fill_step = {}, None
+    if not chain and not args.no_aux:
+        aux = auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, sg, geom, p, out, out_ptrs, ws, hip_event, elapsed_ms)
+    if not chain and not args.no_fill_step:
+        torch.cuda.empty_cache()                                               # config 5 wants 162 GB + headroom
+        fill_step = fill_step_config5(torch, osg, _lib, tlib, dev)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # cells of one step: the whole globe (all bands) -- in loop-back only this band's share of it exists
@@ -735,6 +844,8 @@ def main():
                                        "precompute + fill_halo_regions! of c/u/v/zeta (zipper on the north rank, periodic-x, RCCL y-seam exchange)")),
                        "global_size": list(gsize), "local_size": [NX, ny, NZ], "rows_per_rank": ny, "halo": [H, H, H],
                        "fields": [s[0] for s in SPECS], "parallelism": f"latitude-bands x{bands}" + (" (loop-back: one band on one GPU)" if loopback else "")},
+            "clock_preroll": preroll,
+            "ms_per_step_cold_onset": cold_onset["ms_per_step"] if cold_onset else None, "cold_onset": cold_onset,
             "precompute_cells_per_s": cells / (t_build * 1e-3),            # N > 1: all bands / the slowest rank's build
             "precompute_ms": t_build, "fill_ms": t_fill_kernel, "fill_bracket_ms": t_fill_bracket,
             "fill_GBps": fill_bytes / (t_fill_kernel * 1e-3) / 1e9 if t_fill_kernel else None,
@@ -828,14 +939,29 @@ def main():
             dist.barrier()
         dog.disarm()
         # every rank is past the last collective and the line is out: a communicator that will not shut down must not turn the run
-        # into a failure (or keep the launcher waiting) -- leave with status 0 after 30 s whatever the teardown is doing
-        t_exit = threading.Timer(30.0, lambda: os._exit(0))
+        # into a failure (or keep the launcher waiting) -- but it must not pass unseen either: after 30 s the rank says on stderr which
+        # call it is stuck in (one JSON line, event "teardown_stalled") and leaves with status 0, the measurement being complete
+        pending = ["comm.destroy (ncclCommDestroy)" if comm is not None else "torch.distributed destroy_process_group"]
+
+        def _stalled():
+            print(json.dumps({"event": "teardown_stalled", "rank": rank, "world": world, "phase": "teardown", "pending_call": pending[0],
+                              "after_s": 30, "exit_status": 0, "note": "the contract line was already written; only the shutdown hung"}),
+                  file=sys.stderr, flush=True)
+            os._exit(0)
+
+        t_exit = threading.Timer(float(os.environ.get("TPG_BENCH_TEARDOWN_S", "30")), _stalled)
         t_exit.daemon = True
         t_exit.start()
+        if os.environ.get("TPG_BENCH_TEST_STALL_TEARDOWN") == str(rank):      # tests: a shutdown that never returns
+            time.sleep(3600)
         if comm is not None:
             comm.destroy()
+        pending[0] = "torch.distributed destroy_process_group"
         dist.destroy_process_group()
         t_exit.cancel()
+
+
+AUX_PREROLL = 64
 
 
 def load_traffic():
@@ -929,11 +1055,48 @@ def auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, 
     t_fold32, t_fill32 = statistics.median(a32["fold"][2:]), statistics.median(a32["fill"][2:])
     lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
 
+    # ---- the fold (and the whole fill) of 8 and 16 fields in ONE launch: the caller's real regime (examples/bickley_jet.jl:44-55 fills
+    # u, v, c, eta, U, V ... together; SURVEY.md 7 hard part 3 asks for a batched-fields figure beside cold / warm).  Same geometry as the
+    # headline (3600 x 1800 x 75, halo 4), locations cycling c/u/v/zeta, cold, the kernel's own events, median of 10 after 2 dropped.
+    # The 4-field `roofline_fold` stays the headline; this shows at which field count the fixed ramp + drain of a launch stops mattering.
+    flush = torch.zeros(1 << 27, dtype=torch.float64, device=dev)
+    e0, e1 = hip_event(), hip_event()
+    nb = 16
+    bf = [torch.empty((NZ + 2 * H, NY + 2 * H, NX + 2 * H), dtype=torch.float64, device=dev) for _ in range(nb)]
+    for fid, f in enumerate(bf):
+        testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0xBA7C + fid, 12345.0, *geom, _lib.TPG_F64, None))
+    bspecs = [SPECS[i % len(SPECS)] for i in range(nb)]
+    batched = []
+    for nf in (8, 16):
+        pt = _lib.ptr_table(bf[:nf])
+        bx = (C.c_int8 * nf)(*[q[1] for q in bspecs[:nf]]); by = (C.c_int8 * nf)(*[q[2] for q in bspecs[:nf]]); bs = (C.c_int32 * nf)(*[q[3] for q in bspecs[:nf]])
+        zb = sum(sum(zipper_algorithmic_bytes(NX, NZ, H, [q]).values()) for q in bspecs[:nf])
+        pb = periodic_algorithmic_bytes(NY, NZ, H, nf)
+        tf, tm = [], []
+        for it in range(12):
+            flush.sum()
+            _lib.check(lib.tpg_zipper_fill_timed(pt, nf, bx, by, bs, *geom, 1, NZ, _lib.TPG_F64, stream, e0, e1)); tf.append(elapsed_ms(e0, e1))
+            flush.sum()
+            _lib.check(lib.tpg_fill_halo_regions_timed(pt, nf, bx, by, bs, *geom, 1, _lib.TPG_F64, stream, e0, e1)); tm.append(elapsed_ms(e0, e1))
+        t_f, t_m = statistics.median(tf[2:]), statistics.median(tm[2:])
+        batched.append({"fields": nf, "launch_ms": t_f, "algorithmic_bytes_per_launch": zb, "achieved": zb / (t_f * 1e-3) / 1e9,
+                        "frac": zb / (t_f * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "merged_fill_launch_ms": t_m, "merged_fill_algorithmic_bytes": zb + pb,
+                        "merged_fill_frac": (zb + pb) / (t_m * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+    aux["roofline_fold_batched"] = batched
+    aux["roofline_fold_batched_note"] = ("k_zipper_cols<double,2,4> / k_fill_merged<double,2,4> over 8 and 16 fields of the headline geometry in ONE launch "
+                                         "(locations cycling c/u/v/zeta), cold (after a 1 GiB read-only pass), kernel start/stop events, median of 10; unit GB/s "
+                                         "against the 8000 GB/s peak")
+    del bf, flush
+    lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
+
     def builds():
         """the two build-only measurements: Float32 at 1/10 degree, Float64 at 1/4 degree (BASELINE config 2)"""
         pf = _lib.TpgParams(NX, NY, NZ, H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F32, 1, NY, 0)
         outf = [torch.empty((NY + 2 * H, NX + 2 * H), dtype=torch.float32, device=dev) for _ in _lib.ARRAY_NAMES]
         ptrf = _lib.ptr_table(outf)
+        for _ in range(AUX_PREROLL):                                        # the same declared pre-roll as before the warm-up steps (Float64 builds)
+            _lib.check(lib.tpg_build_grid(C.byref(p), out_ptrs, ws.data_ptr(), ws.numel(), stream))
         for _ in range(3):
             _lib.check(lib.tpg_build_grid(C.byref(pf), ptrf, ws.data_ptr(), ws.numel(), stream))
         b0, b1 = ev(), ev()
@@ -950,8 +1113,8 @@ def auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, 
             "fill_kernel": "k_fill_merged<float,4,4>, same fields, cold, kernel events, median of 10",
             "build_us": usf, "build_cells_per_s": NX * NY / (usf * 1e-6), "build_store_GBps": 80.0 * (NX + 2 * H) * (NY + 2 * H) / (usf * 1e-6) / 1e9,
             "build_note": "3600x1800 Float32 grid: the Float64 pipeline on Float32-rounded lambda tables, rounded once at the store (SURVEY A-1); 20 builds "
-                          "back to back after 3 untimed ones.  This is the first FP64-heavy work after HBM-bound probes, so it sits inside the cell kernel's "
-                          "power-management transient (DESIGN.md 6): ~575-595 us here against ~515 us in steady state"}
+                          f"back to back after a pre-roll of {AUX_PREROLL} Float64 builds + 3 untimed Float32 ones (sustained clocks, like the timed steps)",
+            "preroll_builds": AUX_PREROLL}
         # BASELINE config 2: the 1/4 degree (1440 x 720) Float64 metric precompute alone, 20 back-to-back builds
         p2 = _lib.TpgParams(1440, 720, 1, H, H, H, -80.0, 55.0, 70.0, osg.R_Earth, _lib.TPG_F64, 1, 720, 0)
         out2 = [torch.empty((720 + 2 * H, 1440 + 2 * H), dtype=torch.float64, device=dev) for _ in _lib.ARRAY_NAMES]
@@ -997,17 +1160,7 @@ def auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, 
             "convert_frame_frac_of_hbm_peak": rot_bytes / (t_rot * 1e-6) / 1e9 / HBM_PEAK_GBPS}
         del angle, uo, vo
 
-    # Order of the last two blocks.  The FP64-heavy cell kernel starts a power-management transient whenever it follows lighter work
-    # (first launch 535 us, up to 690 us a few launches later, steady 490 us only after ~25 ms of sustained load).  Round 3 ended
-    # the auxiliary block with the HBM-bound frame rotation (18 ms), so `--steps 20 --warmup 5` timed exactly that transient (0.63-0.65 ms per
-    # step against 0.55 steady).  Now the build measurements (~14 ms of the same FP64 load) run LAST: the timed steps start from the
-    # device's sustained state and a short run reads 0.57 ms.  No step is added and none is skipped; TPG_BENCH_AUX_ORDER=r3 restores the old order
-    # (profiles/r04/aux_order_ab.txt has both, same build, same box).
-    if os.environ.get("TPG_BENCH_AUX_ORDER") == "r3":
-        builds(); geometry()
-    else:
-        geometry(); builds()
-    aux["aux_order"] = "r3: builds, geometry" if os.environ.get("TPG_BENCH_AUX_ORDER") == "r3" else "geometry, builds (FP64-heavy measurements last)"
+    geometry(); builds()
     return aux
 
 

@@ -26,7 +26,7 @@
  *
  *
  * The library reads no environment variable and holds no mutable global state beyond a thread-local error string, the
- * lazily bound librccl entry points (std::call_once) and a thread-local pool of ordering events for the pipelined exchange.  Test / bench hooks (synthetic fill, the copy probe of the fold, the
+ * lazily bound librccl entry points (std::call_once) and a thread-local pool of ordering events for the pipelined exchange (freed with its thread).  Test / bench hooks (synthetic fill, the copy probe of the fold, the
  * elementary-function probe) and the TPG_* cross-check knobs that force the fallback kernels live in a separate
  * library, libtripolar_hip_test.so (include/tripolar_hip_test.h), which a host never loads.
  */
@@ -226,10 +226,16 @@ int tpg_halo_exchange_y_peers(void *comm, int south_peer, int north_peer, void *
  * other pack kernels run beside the first transfer and every unpack but the last beside the next transfer -- what the
  * reference's per-field fill_halo_regions! gets from MPI Isend/Irecv progressing behind the next field's pack
  * (src/distributed_tripolar_grid.jl:171,195 [Oceananigans' transport, recalled]).  Delivers exactly what the monolithic
- * form delivers (same pack / unpack kernels on slices).  On return `stream` is ordered after every transfer and unpack, and
- * comm_stream holds no work `stream` does not wait for.  comm_stream: a second hipStream_t of the caller on the same device
- * (NULL or == stream: the same stages on one stream, no overlap).  All four message buffers are required for every side
- * with a peer (no pack-free form).  The ordering events come from a pool kept per host thread and device (created at the first call). */
+ * form delivers (same pack / unpack kernels on slices).  On return -- WITH ANY STATUS: after a failure that follows the first
+ * group the two streams are joined before the status goes back -- `stream` is ordered after every transfer and unpack that was
+ * enqueued, and comm_stream holds no work `stream` does not wait for; the message buffers may be reused by the next call.
+ * comm_stream: a second hipStream_t of the caller on the same device (NULL or == stream: the same stages on one stream, no
+ * overlap).  All four message buffers are required for every side with a peer (no pack-free form).
+ * ALL RANKS MUST AGREE on nfields and fields_per_stage: group(k) of one rank pairs with group(k) of its neighbour and the two
+ * must carry equal element counts (a mismatch is an RCCL size error or a stall, not detectable from one rank); the Python host
+ * (HaloFillPlan) and bench.py agree on the value once, collectively, before the first exchange.
+ * The ordering events come from a pool kept per host thread and device: created at that thread's first call, destroyed when the
+ * thread ends. */
 int tpg_halo_exchange_y_pipelined(void *comm, int rank, int nranks, void *const fields[], int nfields,
                                   void *send_south, void *send_north, void *recv_south, void *recv_north,
                                   int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,

@@ -14,6 +14,8 @@
  *    TPG_FILL_FUSED           0 never / 1 always (where valid) use the fused small-field fill
  *    TPG_FILL_MERGED          0 never / 1 always (where valid) use the merged large-field fill
  *    TPG_EXCHANGE_IN_CAPTURE  1 lets tpg_halo_exchange_y through on a capturing stream (tools/rccl_capture_probe.py only)
+ *    TPG_EXCHANGE_FAIL_STAGE  k >= 0: tpg_halo_exchange_y_pipelined* returns an injected TPG_ERR_RCCL right after the RCCL group of
+ *                             stage k has been enqueued on comm_stream (error-path post-condition test); -1 / unset: off
  */
 #ifndef TRIPOLAR_HIP_TEST_H
 #define TRIPOLAR_HIP_TEST_H

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libtripolar_hip.so")
 TPG_F32, TPG_F64 = 0, 1
 TPG_CENTER, TPG_FACE = 0, 1
 TPG_MAX_FIELDS = 16
+TPG_BUILD_TABLES_VALID = 1        # tpg_params.reserved flag
 
 # enum tpg_array (order of src/tripolar_grid.jl:308-328 in the reference)
 ARRAY_NAMES = (

@@ -38,6 +38,7 @@ static const Config* read_config()
     c->fill_fused = env_int("TPG_FILL_FUSED", -1);
     c->fill_merged = env_int("TPG_FILL_MERGED", -1);
     c->exchange_in_capture = env_int("TPG_EXCHANGE_IN_CAPTURE", 0) != 0;
+    c->exchange_fail_stage = env_int("TPG_EXCHANGE_FAIL_STAGE", -1);
     return c;
 }
 
@@ -55,7 +56,7 @@ const Config& config()
 // the product library has no knobs: one constant record, no environment access
 const Config& config()
 {
-    static const Config k{ 3, true, 3, -1, -1, false };
+    static const Config k{ 3, true, 3, -1, -1, false, -1 };
     return k;
 }
 #endif

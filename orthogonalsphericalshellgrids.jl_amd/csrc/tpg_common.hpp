@@ -53,6 +53,9 @@ struct Config {
     int fill_merged;          // TPG_FILL_MERGED    -1 automatic (default), 0 never, 1 wherever valid
     bool exchange_in_capture; // TPG_EXCHANGE_IN_CAPTURE  0 (default): the RCCL seam exchange refuses a capturing stream; 1: lets it through
                               //                          (tools/rccl_capture_probe.py, the diagnostic of the round-2 capture stall)
+    int exchange_fail_stage;  // TPG_EXCHANGE_FAIL_STAGE  -1 (default, and always in the product): off; k >= 0: the pipelined seam exchange reports
+                              //                          an injected failure right after the RCCL group of stage k went onto comm_stream
+                              //                          (tests/test_gpu_exchange.py: the error-path post-condition)
 };
 const Config& config();
 

@@ -83,6 +83,38 @@ int nccl_status(const Rccl* r, ncclResult_t e, const char* what)
     return TPG_ERR_RCCL;
 }
 
+// Ordering events of the pipelined exchange: one small pool per (host thread, device), owned by a thread_local object -- the events are
+// destroyed when their thread ends (or, for the main thread, when the process exits: thread_local destructors run before the runtime's own
+// exit handlers).  2 x TPG_MAX_FIELDS stage events + 1 join event for the error path.
+struct EventPools {
+    static constexpr int kMaxDevices = 64, kEvents = 2 * TPG_MAX_FIELDS + 1;
+    struct Pool { hipEvent_t ev[kEvents]; int n = 0; };
+    Pool* pools[kMaxDevices] = {};
+    int get(int device, Pool** out)
+    {
+        if (device < 0 || device >= kMaxDevices) { tpg::set_error("device ordinal %d outside the event pool", device); return TPG_ERR_UNSUPPORTED; }
+        if (!pools[device]) pools[device] = new Pool;
+        Pool& p = *pools[device];
+        while (p.n < kEvents) {                                    // once per thread and device
+            const hipError_t e = hipEventCreateWithFlags(&p.ev[p.n], hipEventDisableTiming);
+            if (e != hipSuccess) return tpg::hip_status(e, "hipEventCreateWithFlags");
+            ++p.n;
+        }
+        *out = &p;
+        return TPG_OK;
+    }
+    ~EventPools()
+    {
+        for (Pool*& p : pools) {
+            if (!p) continue;
+            for (int i = 0; i < p->n; ++i) (void)hipEventDestroy(p->ev[i]);
+            delete p;
+            p = nullptr;
+        }
+    }
+};
+thread_local EventPools t_event_pools;
+
 }  // namespace
 
 extern "C" {
@@ -227,8 +259,11 @@ int tpg_halo_exchange_y_peers(void* comm, int south_peer, int north_peer, void* 
 // fields, 8 bands: 2 x 13 us of pack + 2 x 13 us of unpack against >= 250 us on the link, of which 3/4 can hide.  What is
 // delivered is bit-identical to the monolithic form (same pack / unpack kernels on slices).  When the function returns, `stream`
 // is ordered after every transfer and unpack (its last wait), and comm_stream holds no work that `stream` does not wait for: the
-// message buffers may be reused by the next call on the same pair of streams.  comm_stream = NULL (or = stream) runs the same
-// stages on the one stream (no overlap).  The events that order the two streams come from a thread-local pool (timing disabled).
+// message buffers may be reused by the next call on the same pair of streams -- on error returns as well (a failure after the first
+// group joins the two streams before the status goes back).  comm_stream = NULL (or = stream) runs the same stages on the one stream
+// (no overlap).  The events that order the two streams come from a thread-local pool (timing disabled), destroyed with its thread.
+// EVERY RANK OF THE CHAIN MUST PASS THE SAME fields_per_stage (and nfields): group(k) here pairs with group(k) on the neighbour, with
+// equal element counts; different values give mismatched ncclSend / ncclRecv sizes or a stall.
 int tpg_halo_exchange_y_pipelined_peers(void* comm, int south_peer, int north_peer, void* const fields[], int nfields,
                                         void* send_south, void* send_north, void* recv_south, void* recv_north,
                                         int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft,
@@ -254,30 +289,32 @@ int tpg_halo_exchange_y_pipelined_peers(void* comm, int south_peer, int north_pe
     const size_t per_field = tpg_y_halo_buffer_elems(1, Nx, Nz, Hx, Hy, Hz);
     auto slice = [&](void* base, int f0) -> void* { return base ? static_cast<char*>(base) + (size_t)f0 * per_field * esz : nullptr; };
 
-    // ordering events: a thread-local pool (timing disabled) PER DEVICE -- an event may only be recorded on a stream of the device it was
-    // created on, and one host thread may drive several devices -- created at a thread's first pipelined exchange on that device and kept
-    // for the life of the thread (creating and destroying 2 x stages events per fill cost more host time than the RCCL groups themselves).
-    // Re-recording an event does not disturb a wait enqueued on it earlier (the wait took the state it had then).
-    hipEvent_t *packed_ev = nullptr, *moved_ev = nullptr;
+    // ordering events: a pool (timing disabled) per host thread and DEVICE -- an event may only be recorded on a stream of the device it was
+    // created on, and one host thread may drive several devices -- created at a thread's first pipelined exchange on that device and owned
+    // by a thread_local object whose destructor destroys them when the thread ends (creating and destroying 2 x stages events per fill cost
+    // more host time than the RCCL groups themselves).  Re-recording an event does not disturb a wait enqueued on it earlier (the wait took
+    // the state it had then).
+    hipEvent_t *packed_ev = nullptr, *moved_ev = nullptr, join_ev = nullptr;
     if (two) {
-        constexpr int kMaxDevices = 64;
-        struct Pool { hipEvent_t ev[2 * TPG_MAX_FIELDS]; int n; };
-        static thread_local Pool* pools[kMaxDevices] = {};
         int device = 0;
-        hipError_t de = hipGetDevice(&device);
+        const hipError_t de = hipGetDevice(&device);
         if (de != hipSuccess) return tpg::hip_status(de, "hipGetDevice");
-        if (device < 0 || device >= kMaxDevices) { tpg::set_error("device ordinal %d outside the event pool", device); return TPG_ERR_UNSUPPORTED; }
-        if (!pools[device]) pools[device] = new Pool{ {}, 0 };          // one small record per (thread, device), never freed
-        Pool& pool = *pools[device];
-        while (pool.n < 2 * TPG_MAX_FIELDS) {                            // once per thread and device
-            const hipError_t ee = hipEventCreateWithFlags(&pool.ev[pool.n], hipEventDisableTiming);
-            if (ee != hipSuccess) return tpg::hip_status(ee, "hipEventCreateWithFlags");
-            ++pool.n;
-        }
-        packed_ev = pool.ev; moved_ev = pool.ev + TPG_MAX_FIELDS;
+        EventPools::Pool* pool = nullptr;
+        if ((rc = t_event_pools.get(device, &pool))) return rc;
+        packed_ev = pool->ev; moved_ev = pool->ev + TPG_MAX_FIELDS; join_ev = pool->ev[2 * TPG_MAX_FIELDS];
     }
-    auto destroy_events = []() {};
-#define TPG_PIPE_CHECK(expr) do { if ((rc = (expr))) { destroy_events(); return rc; } } while (0)
+    // Post-condition on EVERY return, error returns included: `stream` is ordered after everything this call has put on comm_stream.
+    // `groups_on_cs` counts the RCCL groups enqueued there so far; a failure after the first one joins the two streams (one event on
+    // comm_stream, one wait on `stream`; their own status is ignored -- the first error is the one reported) before the status goes back.
+    int groups_on_cs = 0;
+    auto leave = [&](int status) {
+        if (status != TPG_OK && two && groups_on_cs > 0) {
+            if (hipEventRecord(join_ev, cs) == hipSuccess) (void)hipStreamWaitEvent(s, join_ev, 0);
+            (void)hipGetLastError();
+        }
+        return status;
+    };
+#define TPG_PIPE_CHECK(expr) do { if ((rc = (expr))) return leave(rc); } while (0)
     // every pack first: they depend on nothing but the local fill that precedes the call on `stream`
     for (int k = 0; k < nstages; ++k) {
         const int f0 = k * fps, n = nfields - f0 < fps ? nfields - f0 : fps;
@@ -298,8 +335,13 @@ int tpg_halo_exchange_y_pipelined_peers(void* comm, int south_peer, int north_pe
         if (south_peer >= 0 && e == ncclSuccess) e = r->Recv(slice(recv_south, f0), msg, dt, south_peer, c, cs);
         if (north_peer >= 0 && e == ncclSuccess) e = r->Recv(slice(recv_north, f0), msg, dt, north_peer, c, cs);
         ncclResult_t e2 = r->GroupEnd();
+        ++groups_on_cs;                                              // whatever GroupEnd says, part of the group may be on comm_stream
         TPG_PIPE_CHECK(nccl_status(r, e, "ncclSend/ncclRecv"));
         TPG_PIPE_CHECK(nccl_status(r, e2, "ncclGroupEnd"));
+        if (tpg::config().exchange_fail_stage == k) {                // test library only (TPG_EXCHANGE_FAIL_STAGE); -1 in the product
+            tpg::set_error("injected failure after the RCCL group of stage %d (TPG_EXCHANGE_FAIL_STAGE)", k);
+            return leave(TPG_ERR_RCCL);
+        }
         if (two) {
             TPG_PIPE_CHECK(tpg::hip_status(hipEventRecord(moved_ev[k], cs), "hipEventRecord"));
             TPG_PIPE_CHECK(tpg::hip_status(hipStreamWaitEvent(s, moved_ev[k], 0), "hipStreamWaitEvent"));

@@ -207,6 +207,23 @@ def _tables(fs):
     return (C.c_int8 * n)(*xl), (C.c_int8 * n)(*yl), (C.c_int32 * n)(*sg)
 
 
+def _agree_across_ranks(arch, value, what):
+    """One collective at plan build: every rank of the chain must hold the same `value` (the stage layout of the seam exchange --
+    group(k) of a rank pairs with group(k) of its neighbour, include/tripolar_hip.h).  Needs torch.distributed initialised over the
+    same ranks as the chain; a host that ferried the RCCL id some other way vouches for the agreement itself."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    group = getattr(arch, "process_group", None)
+    if dist.get_world_size(group) != arch.ranks[1]:
+        return                                  # not the chain's own group (e.g. one process emulating a band of a longer chain)
+    vals = [None] * arch.ranks[1]
+    dist.all_gather_object(vals, value, group=group)
+    if any(v != vals[0] for v in vals):
+        raise ValueError(f"HaloFillPlan: the ranks of the latitude-band chain disagree on {what}: {vals} "
+                         "(every rank must pass the same fields, pack_free and fields_per_stage)")
+
+
 class HaloFillPlan:
     """fill_halo_regions!(fields...) with everything that does not change from call to call -- grouping by
     geometry, location / sign tables, pointer tables -- built once.  A halo fill runs every (sub-)step on
@@ -251,6 +268,8 @@ class HaloFillPlan:
                 # fill_halo_regions! -- zipper (last rank) -> periodic x -> RCCL seam exchange -- on the current stream
                 from .distributed import NORTH, SOUTH, SeamBuffers, exchange_plan, message_shape
                 plan = exchange_plan(arch.local_rank, arch.ranks[1])
+                _agree_across_ranks(arch, (len(fs), geom[0], geom[2:], bool(pack_free), self._fields_per_stage),
+                                    "(fields, Nx, Nz + halos, pack_free, fields_per_stage) of a seam exchange")
                 for b0 in range(0, len(fs), _lib.TPG_MAX_FIELDS):
                     batch = fs[b0:b0 + _lib.TPG_MAX_FIELDS]
                     xl, yl, sg = _tables(batch) if zip_fs else (None, None, None)

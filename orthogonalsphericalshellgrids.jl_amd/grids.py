@@ -6,7 +6,9 @@ one call of tpg_build_grid (HIP, include/tripolar_hip.h) writing the 20 padded a
 device memory.  torch is used for device allocations / streams only.
 """
 import ctypes as C
+import threading
 import unicodedata
+import weakref
 from dataclasses import dataclass
 from typing import Any, Optional, Sequence, Tuple
 
@@ -151,6 +153,8 @@ class OrthogonalSphericalShellGrid:
     global_size: Optional[Tuple[int, int, int]] = None   # distributed grids: size of the global grid
     jrange: Optional[Tuple[int, int]] = None              # distributed grids: owned global rows
     z_spec: Any = (0, 1)
+    workspace: Any = None            # TableWorkspace: the 1-D tables tpg_build_grid left behind, kept for builds of the same geometry
+    tables_reused: bool = False      # this grid was built with TPG_BUILD_TABLES_VALID (its table kernel was skipped)
 
     def __getattr__(self, name):
         arrays = self.__dict__.get("arrays", {})
@@ -250,8 +254,31 @@ def local_row_range(Ny, arch):
     return jstart, jend
 
 
+class TableWorkspace:
+    """The workspace of tpg_build_grid with the 1-D tables of ONE geometry in it, kept with the grid that built them.  `key` is exactly
+    what the tables depend on (include/tripolar_hip.h, TPG_BUILD_TABLES_VALID): global Nx, Ny, Hy, element type, southernmost latitude,
+    north-poles latitude, radius -- and the device.  jstart / jend, Hx, Hz, Nz and first_pole_longitude do not enter.  A build whose key
+    matches runs with the flag set (the ~9 us table kernel is skipped); any other build gets a NEW workspace, so the tables of a live
+    grid are never overwritten.  `ready` orders a reusing build on another stream after the kernel that wrote the tables."""
+
+    def __init__(self, key, tensor):
+        self.key, self.tensor, self.ready = key, tensor, None
+
+
+# live workspaces by key (weak: a workspace lives exactly as long as a grid that holds it): consecutive band builds of one geometry --
+# every rank's band in an emulated chain, reconstruct_global_grid after a band build, with_halo with a new Hx / Hz -- find the tables of
+# the first one
+_live_workspaces = weakref.WeakValueDictionary()
+_live_lock = threading.Lock()
+
+
+def table_key(Nx, Ny, Hy, dtype, southernmost_latitude, north_poles_latitude, radius, device):
+    return (int(Nx), int(Ny), int(Hy), _lib.ft_of(dtype), float(southernmost_latitude), float(north_poles_latitude), float(radius),
+            str(device))
+
+
 def _build(arch, dtype, size, halo, southernmost_latitude, radius, z, north_poles_latitude,
-           first_pole_longitude, jstart, jend, topology_y, global_size=None):
+           first_pole_longitude, jstart, jend, topology_y, global_size=None, tables_from=None):
     Nx, Ny, Nz = (int(s) for s in size)
     Hx, Hy, Hz = (int(h) for h in halo)
     if Nx % 2 == 1:
@@ -262,15 +289,31 @@ def _build(arch, dtype, size, halo, southernmost_latitude, radius, z, north_pole
     p = _lib.TpgParams(Nx, Ny, Nz, Hx, Hy, Hz, float(southernmost_latitude), float(north_poles_latitude),
                        float(first_pole_longitude), float(radius), _lib.ft_of(dtype), jstart, jend, 0)
     rows = jend - jstart + 1 + 2 * Hy
+    key = table_key(Nx, Ny, Hy, dtype, southernmost_latitude, north_poles_latitude, radius, device)
     with torch.cuda.device(device):
         arrays = {n: torch.empty((rows, Nx + 2 * Hx), dtype=dtype, device=device) for n in ARRAY_NAMES}
-        nbytes = lib.tpg_build_grid_workspace_bytes(C.byref(p))
-        workspace = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        nbytes = max(int(lib.tpg_build_grid_workspace_bytes(C.byref(p))), 256)
+        stream = torch.cuda.current_stream(device)
+        # tables of the same geometry already in a live workspace?  (the grid we were derived from, else any live grid's)
+        ws = tables_from if (tables_from is not None and tables_from.key == key) else None
+        if ws is None:
+            with _live_lock:
+                ws = _live_workspaces.get(key)
+        reuse = ws is not None and ws.tensor.numel() >= nbytes and ws.ready is not None
+        if reuse:
+            p.reserved = _lib.TPG_BUILD_TABLES_VALID
+            stream.wait_event(ws.ready)                  # the tables may have been written on another stream
+        else:
+            ws = TableWorkspace(key, torch.empty(nbytes, dtype=torch.uint8, device=device))
         out = _lib.ptr_table([arrays[n] for n in ARRAY_NAMES])
-        _lib.check(lib.tpg_build_grid(C.byref(p), out, workspace.data_ptr(), workspace.numel(),
-                                      _lib.current_stream_ptr(device)))
+        _lib.check(lib.tpg_build_grid(C.byref(p), out, ws.tensor.data_ptr(), ws.tensor.numel(), C.c_void_p(stream.cuda_stream)))
         # the workspace must outlive the asynchronous kernels: tie its release to the stream
-        workspace.record_stream(torch.cuda.current_stream(device))
+        ws.tensor.record_stream(stream)
+        if not reuse:
+            ws.ready = torch.cuda.Event()
+            ws.ready.record(stream)
+            with _live_lock:
+                _live_workspaces[key] = ws
         Lz, zf, zc = _z_coordinate(z, Nz, Hz, dtype, device)
     ny = jend - jstart + 1
     return OrthogonalSphericalShellGrid(
@@ -278,11 +321,12 @@ def _build(arch, dtype, size, halo, southernmost_latitude, radius, z, north_pole
         z_faces=zf, z_centers=zc, radius=float(radius),
         conformal_mapping=Tripolar(north_poles_latitude, first_pole_longitude, southernmost_latitude),
         topology=(PeriodicTopology, topology_y, Bounded), dtype=dtype,
-        global_size=global_size, jrange=(jstart, jend) if global_size else None, z_spec=z)
+        global_size=global_size, jrange=(jstart, jend) if global_size else None, z_spec=z,
+        workspace=ws, tables_reused=reuse)
 
 
 def TripolarGrid(arch=None, FT=torch.float64, *, size, southernmost_latitude=-80, halo=(4, 4, 4),
-                 radius=R_Earth, z=(0, 1), north_poles_latitude=55, first_pole_longitude=70):
+                 radius=R_Earth, z=(0, 1), north_poles_latitude=55, first_pole_longitude=70, _tables_from=None):
     """TripolarGrid(arch, FT; size, southernmost_latitude = -80, halo = (4, 4, 4), radius = R_Earth,
                  z = (0, 1), north_poles_latitude = 55, first_pole_longitude = 70)
 
@@ -291,6 +335,9 @@ def TripolarGrid(arch=None, FT=torch.float64, *, size, southernmost_latitude=-80
     OrthogonalSphericalShellGrid{Periodic, RightConnected, Bounded} whose 20 metric arrays live in
     HBM; on a distributed architecture the rank's band jstart-Hy:jend+Hy is evaluated directly
     (the reference builds the whole globe on every rank and slices it).
+
+    `_tables_from` (not a reference keyword; with_halo / reconstruct_global_grid pass it) names a TableWorkspace whose 1-D tables may be
+    reused if they are of this geometry; without it a live grid of the same geometry is found by key.  Results are identical either way.
     """
     arch = GPU() if arch is None else arch
     dtype = _torch_dtype(FT)
@@ -303,10 +350,10 @@ def TripolarGrid(arch=None, FT=torch.float64, *, size, southernmost_latitude=-80
         jstart, jend = local_row_range(Ny, arch)
         LY = RightConnected if arch.local_rank == 0 else FullyConnected      # :75
         return _build(arch, dtype, size, halo, southernmost_latitude, radius, z, north_poles_latitude,
-                      first_pole_longitude, jstart, jend, LY, global_size=tuple(size))
+                      first_pole_longitude, jstart, jend, LY, global_size=tuple(size), tables_from=_tables_from)
     Nx, Ny, Nz = size
     return _build(arch, dtype, size, halo, southernmost_latitude, radius, z, north_poles_latitude,
-                  first_pole_longitude, 1, Ny, RightConnected)
+                  first_pole_longitude, 1, Ny, RightConnected, tables_from=_tables_from)
 
 
 def x_domain(grid):
@@ -322,10 +369,12 @@ def y_domain(grid):
 
 def with_halo(new_halo, old_grid):
     """with_halo(new_halo, grid)  (src/with_halo.jl:5-44): re-run the constructor from the stored
-    Tripolar parameters with a different halo."""
+    Tripolar parameters with a different halo.  The old grid's 1-D tables are reused (TPG_BUILD_TABLES_VALID) when only Hx / Hz change;
+    a new Hy -- or, distributed method, the default radius replacing a custom one -- changes the table key and recomputes them."""
     cm = old_grid.conformal_mapping
     kw = dict(z=old_grid.z_spec, halo=new_halo, north_poles_latitude=cm.north_poles_latitude,
-              first_pole_longitude=cm.first_pole_longitude, southernmost_latitude=cm.southernmost_latitude)
+              first_pole_longitude=cm.first_pole_longitude, southernmost_latitude=cm.southernmost_latitude,
+              _tables_from=old_grid.workspace)
     if old_grid.global_size:
         # distributed method (src/with_halo.jl:25-44) does not forward `radius` (reference quirk kept)
         return TripolarGrid(old_grid.architecture, old_grid.dtype, size=old_grid.global_size, **kw)
@@ -333,9 +382,10 @@ def with_halo(new_halo, old_grid):
 
 
 def reconstruct_global_grid(grid):
-    """reconstruct_global_grid(grid::DistributedTripolarGrid)  (src/distributed_tripolar_grid.jl:201-226)"""
+    """reconstruct_global_grid(grid::DistributedTripolarGrid)  (src/distributed_tripolar_grid.jl:201-226); the band's 1-D tables are
+    those of the globe (they are indexed by global row), so the global build reuses them"""
     cm = grid.conformal_mapping
-    return TripolarGrid(child_architecture(grid.architecture), grid.dtype, halo=grid.halo_size,
+    return TripolarGrid(child_architecture(grid.architecture), grid.dtype, halo=grid.halo_size, _tables_from=grid.workspace,
                         size=grid.global_size if grid.global_size else grid.size, z=grid.z_spec,
                         north_poles_latitude=cm.north_poles_latitude,
                         first_pole_longitude=cm.first_pole_longitude,

@@ -134,3 +134,43 @@ def test_rccl_readiness_is_agreed_before_the_collective_init():
         r, msg = results.get()
         got[r] = msg
     assert set(got) == {0, 1, 2} and all("librccl unavailable on rank(s) [1]" in m for m in got.values()), got
+
+
+def _stage_agreement_worker(rank, world, port, results):
+    """HaloFillPlan's one collective at plan build: ranks that disagree on the stage layout of the pipelined seam exchange (group(k) of
+    a rank pairs with group(k) of its neighbour, include/tripolar_hip.h) must ALL leave with a ValueError -- before any RCCL group"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import orthogonalsphericalshellgrids.jl_amd as osg
+    from orthogonalsphericalshellgrids.jl_amd.fields import _agree_across_ranks
+    arch = osg.Distributed(osg.GPU(), osg.Partition(y=world))
+    _agree_across_ranks(arch, (4, 3600, (75, 4, 4, 4), False, 2), "stage layout")            # equal everywhere: passes
+    try:
+        _agree_across_ranks(arch, (4, 3600, (75, 4, 4, 4), False, 2 if rank != 1 else 1), "stage layout")
+        results.put((rank, "no error"))
+    except ValueError as e:
+        results.put((rank, str(e)))
+    longer = osg.Distributed(osg.GPU(), osg.Partition(y=8), local_rank=3)                    # not this group's chain: no collective, no error
+    _agree_across_ranks(longer, rank, "anything")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_must_agree_on_the_stage_layout_of_the_pipelined_exchange():
+    world = 3
+    ctx = mp.get_context("spawn")
+    results = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stage_agreement_worker, args=(r, world, port, results)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = {}
+    while not results.empty():
+        r, msg = results.get()
+        got[r] = msg
+    assert set(got) == {0, 1, 2} and all("disagree on stage layout" in m for m in got.values()), got

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_contract_line(gpu):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--preroll", "8"],
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -55,8 +55,21 @@ def test_bench_prints_one_contract_line(gpu):
     f32 = d["float32"]                               # the reference tests both element types (test/runtests.jl:10)
     assert f32["fold_algorithmic_bytes"] == zb // 2 and 0 < f32["fold_ms"] < d["zipper_cold_ms"] * 1.2
     assert f32["fill_algorithmic_bytes"] == (zb + pb) // 2 and f32["build_cells_per_s"] > 1e9
-    assert "prewarm_steps" not in d                  # exactly W warm-up steps
-    assert d["aux_order"].startswith("geometry, builds")   # which auxiliary measurement precedes the warm-up is part of the line
+    # what precedes the W warm-up steps is DECLARED, not implied by a missing key: the clock pre-roll with its build count (here the
+    # --preroll 8 of the command line; default 64) and nothing else -- every auxiliary measurement runs after the timed region
+    pre = d["clock_preroll"]
+    assert pre["builds"] == 8 and pre["ms"] > 0 and "tpg_build_grid" in pre["what"] and "aux_order" not in d and "prewarm_steps" not in d
+    assert f32["preroll_builds"] == 64 and "pre-roll" in f32["build_note"]
+    co = d["cold_onset"]                             # the same K steps right after >= 50 ms of HBM-bound work: a caller's first builds
+    assert d["ms_per_step_cold_onset"] == co["ms_per_step"] > 0 and co["steps"] == 3 and co["preceded_by_ms_of_hbm_bound_work"] >= 50
+    assert 0.3 * d["ms_per_step"] < d["ms_per_step_cold_onset"] < 3 * d["ms_per_step"]
+    # SURVEY 7 hard part 3: the batched-fields fold beside the 4-field headline, same geometry, one launch of 8 and of 16 fields
+    fb = d["roofline_fold_batched"]
+    assert [b["fields"] for b in fb] == [8, 16] and [b["algorithmic_bytes_per_launch"] for b in fb] == [2 * zb, 4 * zb]
+    for b in fb:
+        assert abs(b["frac"] - b["achieved"] / 8000.0) < 1e-12 and f["frac"] * 0.8 < b["frac"] < 1.0
+        assert b["merged_fill_algorithmic_bytes"] == (zb + pb) * b["fields"] // 4 and 0.1 < b["merged_fill_frac"] < 1.0
+    assert fb[1]["launch_ms"] > fb[0]["launch_ms"] > f["launch_ms"]
     assert "exchange_ms" not in d and "periodic_x" not in d and "line_frac_of_hbm_peak" not in json.dumps(d)
     # config 5: the fills of one baroclinic step at 1/24 degree x 100 levels
     fs = d["fill_step"]
@@ -130,6 +143,36 @@ def test_bench_four_ranks_rehearsal_interior_ranks_verify_both_seams(gpu):
     assert [r["seams"] for r in pr] == [1, 2, 2, 1] and [r["zipper"] for r in pr] == [False, False, False, True]
     assert all(r["seams_bit_exact"] for r in pr) and "bit for bit" in d["seam_check"]
     assert abs(d["value"] - 3600 * 1800 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_five_ranks_rehearsal_the_most_one_card_allows(gpu):
+    """`python bench.py --gpus 5` (self-started workers, gloo rehearsal): the box's process guard allows 6 processes on the card and this
+    test process is one of them, so five ranks is the longest chain rehearsed WITH kernels from inside the suite -- three interior ranks
+    with two seams each, 360 rows per rank.  BASELINE config 4's own N = 8 start-up (225 rows, six two-seam ranks) is
+    tests/test_bench_startup.py (device-free) and its band geometry with the real kernels is tests/test_gpu_distributed.py (8 emulated
+    ranks in one process) and the --loopback runs below (bands 3 and 7 of 8 over RCCL)."""
+    d = _two_rank_bench([], ranks=5)
+    assert d["n_gpus"] == 5 and d["config"]["rows_per_rank"] == 360 and d["config"]["parallelism"] == "latitude-bands x5"
+    pr = d["per_rank"]
+    assert [r["rows"] for r in pr] == [[360 * r + 1, 360 * r + 360] for r in range(5)]
+    assert [r["seams"] for r in pr] == [1, 2, 2, 2, 1] and [r["zipper"] for r in pr] == [False] * 4 + [True]
+    assert all(r["seams_bit_exact"] for r in pr)
+    assert d["clock_preroll"]["builds"] == 64 * 5 and d["ms_per_step_cold_onset"] is None
+
+
+def test_bench_stalled_teardown_is_reported(gpu):
+    """A communicator / process-group shutdown that never returns (TPG_BENCH_TEST_STALL_TEARDOWN on rank 1 of a two-rank rehearsal, 3 s
+    limit): the contract line is already out, the job still exits 0 -- and rank 1 says on stderr which call it was stuck in."""
+    env = dict(os.environ, TPG_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1", TPG_BENCH_TEST_STALL_TEARDOWN="1", TPG_BENCH_TEARDOWN_S="3")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len([l for l in p.stdout.splitlines() if l.startswith('{"metric"')]) == 1
+    diag = [json.loads(l) for l in p.stderr.splitlines() if l.startswith("{") and "teardown_stalled" in l]
+    d1 = [x for x in diag if x["rank"] == 1]
+    assert len(d1) == 1 and d1[0]["phase"] == "teardown" and "destroy" in d1[0]["pending_call"] and d1[0]["exit_status"] == 0
 
 
 @pytest.mark.parametrize("band", [3, 7])

@@ -32,6 +32,13 @@ def test_rccl_seam_exchange_single_rank_loopback(gpu):
     assert d["pipelined"]["cases"] >= 40 and d["pipelined"]["all_bit_exact"], d["pipelined"]["failed"][:3]
     assert set(d["exchange_cost_config4_band_loopback"]) == {"monolithic", "pipelined_1", "pipelined_2"}
     assert d["two_streams_own_buffers_bit_exact"] is True
+    # a failure injected after the RCCL group of stage 1 (test library): TPG_ERR_RCCL comes back, `stream` is nevertheless ordered after
+    # everything on comm_stream (post-condition of include/tripolar_hip.h on error returns), and the same buffers then serve a good call
+    lf = d["late_failure"]
+    assert lf["rcs"] == [-7] * 5 and all(lf["comm_stream_idle_after_stream_sync"]) and lf["rc_after"] == 0 and lf["reuse_bit_exact"]
+    assert len(lf["messages"]) == 1 and "injected failure after the RCCL group of stage 1" in lf["messages"][0]
+    # the ordering events belong to their host thread (thread_local owner): threads that exchange and end leave the others untouched
+    assert d["event_pool_threads"] == {"thread_rcs": [0, 0, 0], "main_rc_after": 0}
     # a capturing stream is refused instead of stalling, and the capture survives the refusal
     f = d["capture_fence"]
     assert f["rc"] == -5 and f["rc_pipelined"] == -5 and "captured" in f["message"] and f["periodic_rc_in_capture"] == 0 and f["replay_bit_exact"]

@@ -224,6 +224,65 @@ def main():
     out["capture_fence"] = {"rc": rc_fence, "rc_pipelined": rc_fence_p, "message": msg, "periodic_rc_in_capture": rc_per, "replay_bit_exact": bool(torch.equal(d2, want))}
     out["ok"] = out["ok"] and rc_fence == -5 and rc_fence_p == -5 and rc_per == 0 and out["capture_fence"]["replay_bit_exact"]
 
+    # ---- a LATE failure of the pipelined exchange (test library, TPG_EXCHANGE_FAIL_STAGE=1: injected right after the RCCL group of stage 1
+    #      went onto comm_stream): the call returns TPG_ERR_RCCL, and its post-condition must hold all the same -- `stream` is ordered after
+    #      everything on comm_stream (synchronising `stream` alone leaves comm_stream idle), so the SAME buffers and streams serve the
+    #      next, successful call.  Config 4's band, 4 stages of one field (a stage's transfers take tens of microseconds). ----------------
+    from tools import testlib
+    tl = testlib.lib()
+    (Nx, Ny, Nz), (Hx, Hy, Hz), nf = (3600, 225, 75), (4, 4, 4), 4
+    shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
+    nbuf = lib.tpg_y_halo_buffer_elems(nf, Nx, Nz, Hx, Hy, Hz)
+    bufs = [torch.empty(nbuf, dtype=torch.float64, device=dev) for _ in range(4)]
+    bp, csp = [b.data_ptr() for b in bufs], C.c_void_p(comm_stream.cuda_stream)
+    main_stream = torch.cuda.current_stream()
+    stream = _lib.current_stream_ptr(dev)
+    late = {"rcs": [], "comm_stream_idle_after_stream_sync": [], "messages": set()}
+    os.environ["TPG_EXCHANGE_FAIL_STAGE"] = "1"
+    testlib.check(tl.tpg_reload_config())
+    devs = [torch.rand(shape, dtype=torch.float64, device=dev) for _ in range(nf)]
+    torch.cuda.synchronize()
+    for trial in range(5):
+        rc = tl.tpg_halo_exchange_y_pipelined_peers(comm.handle, 0, 0, _lib.ptr_table(devs), nf, *bp, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream, csp, 1)
+        late["messages"].add(tl.tpg_last_error().decode())
+        main_stream.synchronize()                                      # `stream` only
+        late["comm_stream_idle_after_stream_sync"].append(bool(comm_stream.query()))
+        late["rcs"].append(rc)
+        torch.cuda.synchronize()
+    del os.environ["TPG_EXCHANGE_FAIL_STAGE"]
+    testlib.check(tl.tpg_reload_config())
+    before = [d.clone() for d in devs]
+    rc_after = tl.tpg_halo_exchange_y_pipelined_peers(comm.handle, 0, 0, _lib.ptr_table(devs), nf, *bp, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream, csp, 1)
+    torch.cuda.synchronize()
+    good = rc_after == 0
+    for b, d in zip(before, devs):
+        want = b.clone()
+        want[:, :Hy] = b[:, Ny:Ny + Hy]; want[:, Ny + Hy:] = b[:, Hy:2 * Hy]
+        good = good and bool(torch.equal(d, want))
+    late.update(rc_after=rc_after, reuse_bit_exact=bool(good), messages=sorted(late["messages"]))
+    out["late_failure"] = late
+    out["ok"] = out["ok"] and good and late["rcs"] == [-7] * 5 and all(late["comm_stream_idle_after_stream_sync"])
+
+    # ---- the ordering-event pool belongs to its host thread: a short-lived thread runs a pipelined exchange and ends (its events are
+    #      destroyed by the thread_local owner), the main thread's pool keeps working ---------------------------------------------------
+    import threading
+    th_rc = []
+
+    def in_thread():
+        torch.cuda.set_device(0)
+        cs2 = torch.cuda.Stream(dev)
+        with torch.cuda.stream(torch.cuda.Stream(dev)):
+            th_rc.append(lib.tpg_halo_exchange_y_pipelined_peers(comm.handle, 0, 0, _lib.ptr_table(devs), nf, *bp, Nx, Ny, Nz, Hx, Hy, Hz, 1,
+                                                                 _lib.current_stream_ptr(dev), C.c_void_p(cs2.cuda_stream), 2))
+            torch.cuda.synchronize()
+
+    for _ in range(3):
+        t = threading.Thread(target=in_thread); t.start(); t.join()
+    rc_main = lib.tpg_halo_exchange_y_pipelined_peers(comm.handle, 0, 0, _lib.ptr_table(devs), nf, *bp, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream, csp, 2)
+    torch.cuda.synchronize()
+    out["event_pool_threads"] = {"thread_rcs": th_rc, "main_rc_after": rc_main}
+    out["ok"] = out["ok"] and th_rc == [0, 0, 0] and rc_main == 0
+
     # the chain rule: a one-rank chain has no seam
     d = torch.zeros((1, 12, 12), dtype=torch.float64, device=dev)
     out["single_rank_chain_rc"] = lib.tpg_halo_exchange_y(comm.handle, 0, 1, _lib.ptr_table([d]), 1, None, None, None, None, 4, 4, 1, 4, 4, 0, 1, None)
