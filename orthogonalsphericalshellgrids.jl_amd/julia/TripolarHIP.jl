@@ -12,6 +12,13 @@
 # minimal DenseArray over hipMalloc / hipFree / hipMemcpy, called through `ccall` on libamdhip64, and `HIPGPU()` is the
 # Oceananigans architecture value that carries it.  `device_pointer` accepts nothing but (views / OffsetArrays of) a HIPArray: no
 # path in this file can hand a host pointer or a CuArray to a `tpg_*` entry point.
+#
+# LIMIT of HIPGPU(): it is an architecture for THIS path only.  It has no KernelAbstractions backend, so Oceananigans' own kernels
+# (tendencies, its south / bottom / top halo fills, generic `fill_halo_regions!`) cannot launch on a grid built there; every place in
+# this file that would have to hand a field to them on HIPGPU() raises an ArgumentError that says so instead of a MethodError.  A
+# whole-model caller keeps its grid and fields in its own backend's device arrays and reaches the `tpg_*` entry points through the three
+# hooks `device_pointer` / `device_array` / `stream_for`, which ext/TripolarHIPBackendExt.jl (a weak-dependency extension, never
+# imported here) defines for that backend: pointer and stream extraction only, no kernels.
 module TripolarHIP
 
 export TripolarGrid, ZipperBoundaryCondition           # src/OrthogonalSphericalShellGrids.jl:4
@@ -89,6 +96,7 @@ end
 #   hipError_t hipMemset(void* dst, int value, size_t sizeBytes);
 #   hipError_t hipStreamCreateWithFlags(hipStream_t* stream, unsigned int flags);
 #   hipError_t hipStreamSynchronize(hipStream_t stream);       hipError_t hipDeviceSynchronize(void);
+#   hipError_t hipStreamDestroy(hipStream_t stream);
 #   const char* hipGetErrorString(hipError_t hipError);
 const hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice = Cint(1), Cint(2), Cint(3)   # enum hipMemcpyKind
 const hipStreamNonBlocking = Cuint(1)
@@ -200,8 +208,9 @@ device_pointer(a) = throw(ArgumentError("libtripolar_hip needs device memory own
                                         "host Arrays and CuArrays are refused"))
 
 # hipStream_t of the calling Julia task: one non-blocking stream per task, created at first use (fills issued from different
-# tasks run on different streams and never share seam buffers, section 5); `use_default_stream!()` selects the NULL stream instead
-const TASK_STREAMS = IdDict{Any, Ptr{Cvoid}}()
+# tasks run on different streams and never share seam buffers, section 5); `use_default_stream!()` selects the NULL stream instead.
+# The handle lives in the task's own `task_local_storage()` -- no table shared between threads, nothing keeps a finished Task alive --
+# and its finalizer returns the stream to the runtime (hipError_t hipStreamDestroy(hipStream_t stream)) when the task is collected.
 const USE_DEFAULT_STREAM = Ref(true)
 use_default_stream!(flag::Bool = true) = (USE_DEFAULT_STREAM[] = flag)
 function new_stream()
@@ -209,8 +218,29 @@ function new_stream()
     hipcheck(ccall((:hipStreamCreateWithFlags, libhip), Cint, (Ref{Ptr{Cvoid}}, Cuint), s, hipStreamNonBlocking))
     return s[]
 end
-current_stream() = USE_DEFAULT_STREAM[] ? C_NULL : get!(new_stream, TASK_STREAMS, current_task())
+mutable struct StreamHandle
+    ptr::Ptr{Cvoid}
+    function StreamHandle()
+        h = new(new_stream())
+        finalizer(destroy_stream!, h)
+        return h
+    end
+end
+function destroy_stream!(h::StreamHandle)
+    h.ptr == C_NULL || ccall((:hipStreamDestroy, libhip), Cint, (Ptr{Cvoid},), h.ptr)       # status ignored: a finalizer must not throw
+    h.ptr = C_NULL
+    return nothing
+end
+task_stream(key::Symbol) = (get!(StreamHandle, task_local_storage(), key)::StreamHandle).ptr
+current_stream() = USE_DEFAULT_STREAM[] ? C_NULL : task_stream(:tripolar_hip_stream)
 synchronize_stream(s = current_stream()) = hipcheck(ccall((:hipStreamSynchronize, libhip), Cint, (Ptr{Cvoid},), s))
+# the stream this library enqueues on for arrays of `arch`: this file's own task stream for HIPGPU(); a backend extension returns its
+# backend's current stream handle, so that the `tpg_*` kernels order themselves with the host model's own kernels
+stream_for(arch) = current_stream()
+stream_for(arch::Distributed) = stream_for(child_architecture(arch))
+
+# process-wide tables of this file (seam communicators, table workspaces) are guarded by one lock: fills may come from several threads
+const STATE_LOCK = ReentrantLock()
 
 # An UNINITIALISED device array (HBM) of that shape: tpg_build_grid overwrites every element of the 20 arrays, halos included,
 # so nothing is zeroed on the host and nothing crosses PCIe.
@@ -241,6 +271,31 @@ const DTRG = Union{DistributedTripolarGrid, ImmersedBoundaryGrid{<:Any, <:Any, <
 # ---------------------------------------------------------------------------------------------------------------------
 # 3. TripolarGrid constructors                         src/tripolar_grid.jl:59-333; distributed_tripolar_grid.jl:24-110
 # ---------------------------------------------------------------------------------------------------------------------
+# The 1-D tables tpg_build_grid leaves in its workspace, kept for later builds of the same geometry (TPG_BUILD_TABLES_VALID,
+# include/tripolar_hip.h): `key` = exactly what the tables depend on -- global Nx, Ny, Hy, element type, southernmost latitude,
+# north-poles latitude, radius -- plus the architecture; jstart / jend, Hx, Hz, Nz and first_pole_longitude do not enter.  A workspace
+# lives as long as a grid built on it: GRID_WORKSPACES is weak in its keys (the grid's lambda_cc parent array), so with_halo (same size,
+# new Hx / Hz: src/with_halo.jl:5-44), reconstruct_global_grid after a band build (src/distributed_tripolar_grid.jl:201-226) and
+# consecutive band builds of one geometry find the tables of the first build, and nothing outlives the grids.  A build whose key differs
+# gets a NEW workspace: the tables of a live grid are never overwritten.
+const TPG_BUILD_TABLES_VALID = Int32(1)
+mutable struct TableWorkspace
+    key::Any
+    buffer::Any                    # device array of tpg_build_grid_workspace_bytes
+    stream::Ptr{Cvoid}             # the stream the table kernel ran on
+end
+const GRID_WORKSPACES = WeakKeyDict{Any, TableWorkspace}()
+table_key(arch, FT, Nλ, Nφ, Hφ, south, npl, radius) = (child_architecture(arch), FT, Int(Nλ), Int(Nφ), Int(Hφ), Float64(south), Float64(npl), Float64(radius))
+function live_workspace(key, nbytes)
+    lock(STATE_LOCK) do
+        for w in values(GRID_WORKSPACES)
+            w.key == key && sizeof(w.buffer) >= nbytes && return w
+        end
+        return nothing
+    end
+end
+table_workspace(grid) = lock(() -> get(GRID_WORKSPACES, parent(grid.λᶜᶜᵃ), nothing), STATE_LOCK)
+
 # ONE tpg_build_grid call fills the 20 padded arrays of the latitude band jstart:jend in HBM (no host passes, no H2D).
 function build_band(arch, FT, size, halo, southernmost_latitude, radius, z, north_poles_latitude, first_pole_longitude,
                     jstart, jend, LY)
@@ -248,17 +303,29 @@ function build_band(arch, FT, size, halo, southernmost_latitude, radius, z, nort
     Hλ, Hφ, Hz = halo
     isodd(Nλ) && throw(ArgumentError("The number of cells in the longitude dimension should be even!"))   # :81-83
     ny = jend - jstart + 1
-    p = Ref(TpgParams(Nλ, Nφ, Nz, Hλ, Hφ, Hz, southernmost_latitude, north_poles_latitude, first_pole_longitude,
-                      radius, ft_code(FT), jstart, jend, 0))
     arrays = [device_array(arch, FT, Nλ + 2Hλ, ny + 2Hφ) for _ in 1:20]
-    nbytes = ccall((:tpg_build_grid_workspace_bytes, libtripolar), Csize_t, (Ref{TpgParams},), p)
-    workspace = device_array(arch, UInt8, Int(nbytes))
+    p0 = Ref(TpgParams(Nλ, Nφ, Nz, Hλ, Hφ, Hz, southernmost_latitude, north_poles_latitude, first_pole_longitude,
+                       radius, ft_code(FT), jstart, jend, 0))
+    nbytes = ccall((:tpg_build_grid_workspace_bytes, libtripolar), Csize_t, (Ref{TpgParams},), p0)
+    s   = stream_for(arch)
+    key = table_key(arch, FT, Nλ, Nφ, Hφ, southernmost_latitude, north_poles_latitude, radius)
+    ws  = live_workspace(key, nbytes)
+    reuse = ws !== nothing
+    if reuse
+        ws.stream == s || synchronize_stream(ws.stream)          # tables written on another stream: wait for them (a build is a one-off)
+    else
+        ws = TableWorkspace(key, device_array(arch, UInt8, Int(nbytes)), s)
+    end
+    p = Ref(TpgParams(Nλ, Nφ, Nz, Hλ, Hφ, Hz, southernmost_latitude, north_poles_latitude, first_pole_longitude,
+                      radius, ft_code(FT), jstart, jend, reuse ? TPG_BUILD_TABLES_VALID : Int32(0)))
+    workspace = ws.buffer
     ptrs = Ptr{Cvoid}[device_pointer(a) for a in arrays]
     GC.@preserve arrays workspace begin
         check(ccall((:tpg_build_grid, libtripolar), Cint,
                     (Ref{TpgParams}, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-                    p, ptrs, device_pointer(workspace), nbytes, current_stream()))
+                    p, ptrs, device_pointer(workspace), nbytes, s))
     end
+    lock(() -> (GRID_WORKSPACES[arrays[1]] = ws), STATE_LOCK)     # arrays[1] = parent of lambda_cc: the grid keeps its tables alive
     # enum tpg_array == positional order of src/tripolar_grid.jl:308-328 (note dy: cc, cf, fc, ff)
     off(a) = OffsetArray(a, -Hλ, -Hφ)
     λcc, λfc, λcf, λff, φcc, φfc, φcf, φff,
@@ -308,7 +375,8 @@ end
 x_domain(grid::TRG) = 0, 360
 y_domain(grid::TRG) = minimum(parent(grid.φᶠᶠᵃ)), 90
 
-# src/with_halo.jl:5-23 (serial) and :25-44 (distributed: `radius` is not forwarded there -- kept)
+# src/with_halo.jl:5-23 (serial) and :25-44 (distributed: `radius` is not forwarded there -- kept).  The constructor finds the old
+# grid's 1-D tables (live_workspace, same key) and builds with TPG_BUILD_TABLES_VALID when only Hx / Hz change; a new Hy changes the key.
 function with_halo(new_halo, old_grid::TripolarGrid)
     cm = old_grid.conformal_mapping
     return TripolarGrid(architecture(old_grid), eltype(old_grid); size = (old_grid.Nx, old_grid.Ny, old_grid.Nz),
@@ -326,7 +394,7 @@ function with_halo(new_halo, old_grid::DistributedTripolarGrid)
                         southernmost_latitude = cm.southernmost_latitude)
 end
 
-# src/distributed_tripolar_grid.jl:201-226
+# src/distributed_tripolar_grid.jl:201-226; the band's 1-D tables are the globe's (indexed by global row): the global build reuses them
 function reconstruct_global_grid(grid::DistributedTripolarGrid)
     arch = grid.architecture
     cm = grid.conformal_mapping
@@ -443,25 +511,23 @@ destroy!(c::SeamComm) = (check(ccall((:tpg_comm_destroy, libtripolar), Cint, (Pt
 # bind librccl (tpg_comm_available: no collective call) and the ranks agree BEFORE the collective ncclCommInitRank; the 128-byte
 # id travels over the architecture's own MPI communicator (`arch.communicator`, `MPI.Allreduce` / `MPI.Bcast!` [recalled]).
 const SEAM_COMMS = IdDict{Any, SeamComm}()
-function seam_comm(arch::Distributed)
-    get!(SEAM_COMMS, arch) do
-        ok = ccall((:tpg_comm_available, libtripolar), Cint, ()) == 0 ? 1 : 0
-        MPI.Allreduce(ok, MPI.MIN, arch.communicator) == 1 || error("librccl cannot be bound on every rank: no seam communicator")
-        id = arch.local_rank == 0 ? comm_unique_id() : zeros(UInt8, 128)
-        MPI.Bcast!(id, 0, arch.communicator)
-        SeamComm(id, arch.local_rank, ranks(arch.partition)[2])
-    end
+function new_seam_comm(arch::Distributed)
+    ok = ccall((:tpg_comm_available, libtripolar), Cint, ()) == 0 ? 1 : 0
+    MPI.Allreduce(ok, MPI.MIN, arch.communicator) == 1 || error("librccl cannot be bound on every rank: no seam communicator")
+    id = arch.local_rank == 0 ? comm_unique_id() : zeros(UInt8, 128)
+    MPI.Bcast!(id, 0, arch.communicator)
+    return SeamComm(id, arch.local_rank, ranks(arch.partition)[2])
 end
+seam_comm(arch::Distributed) = lock(() -> get!(() -> new_seam_comm(arch), SEAM_COMMS, arch), STATE_LOCK)
 
 y_halo_buffer_elems(nfields, grid, Nz, Hz) =
     Int(ccall((:tpg_y_halo_buffer_elems, libtripolar), Csize_t, (Cint, Cint, Cint, Cint, Cint, Cint),
               nfields, size(grid, 1), Nz, halo_size(grid)[1], halo_size(grid)[2], Hz))
 
-# message buffers of one (architecture, nfields, element type, Nz, Hz) fill, kept across fills; one set per Julia task, so that
-# fills issued from different tasks (= different streams) never share staging memory
-const SEAM_BUFFERS = Dict{Any, NTuple{4, Any}}()
+# message buffers of one (architecture, nfields, element type, Nz, Hz) fill, kept across fills in the TASK's own storage: fills issued
+# from different tasks (= different streams) never share staging memory, and the buffers go when their task goes
 function seam_buffers(arch, grid, nfields, FT, Nz, Hz)
-    get!(SEAM_BUFFERS, (arch, nfields, FT, Nz, Hz, size(grid), halo_size(grid), objectid(current_task()))) do
+    get!(task_local_storage(), (:tripolar_hip_seam_buffers, arch, nfields, FT, Nz, Hz, size(grid), halo_size(grid))) do
         n = y_halo_buffer_elems(nfields, grid, Nz, Hz)
         ntuple(_ -> device_array(arch, FT, n), 4)
     end
@@ -535,8 +601,15 @@ const TPG_MAX_FIELDS = 16                      # include/tripolar_hip.h: fields 
 # k fields with the RCCL groups on a second stream (tpg_fill_halo_regions_distributed_pipelined); identical results
 const SEAM_FIELDS_PER_STAGE = Ref(0)
 seam_exchange_pipelined!(fields_per_stage::Integer = 1) = (SEAM_FIELDS_PER_STAGE[] = Int(fields_per_stage))
-const COMM_STREAMS = IdDict{Any, Ptr{Cvoid}}()                  # the second stream of the pipelined exchange, one per Julia task
-comm_stream() = get!(new_stream, COMM_STREAMS, current_task())
+comm_stream() = task_stream(:tripolar_hip_comm_stream)          # the second stream of the pipelined exchange, one per Julia task
+# EVERY RANK must select the same form: group(k) of a rank pairs with group(k) of its neighbour (include/tripolar_hip.h).  The value is a
+# per-process setting; `seam_exchange_pipelined!(k, arch)` with a Distributed architecture checks the agreement once, collectively.
+function seam_exchange_pipelined!(fields_per_stage::Integer, arch::Distributed)
+    k = Int(fields_per_stage)
+    lo, hi = MPI.Allreduce(k, MPI.MIN, arch.communicator), MPI.Allreduce(k, MPI.MAX, arch.communicator)
+    lo == hi || throw(ArgumentError("seam_exchange_pipelined!: ranks disagree on fields_per_stage ($lo .. $hi)"))
+    return SEAM_FIELDS_PER_STAGE[] = k
+end
 
 function hip_fill!(fields, bcs, locs, indices, grid; stage::Symbol, comm = nothing, arch = nothing)
     Nx, Ny, _ = size(grid)
@@ -552,7 +625,7 @@ function hip_fill!(fields, bcs, locs, indices, grid; stage::Symbol, comm = nothi
         sgn  = Int32[zips ? zipper_sign(bcs[n].north) : Int32(1) for n in idx]
         bufs = comm === nothing ? ntuple(_ -> nothing, 4) : seam_buffers(arch, grid, length(fs), FT, Nz, Hz)
         bp   = map(b -> b === nothing ? C_NULL : device_pointer(b), bufs)
-        s    = current_stream()
+        s    = stream_for(arch === nothing ? architecture(grid) : arch)
         fps  = SEAM_FIELDS_PER_STAGE[]
         GC.@preserve fs bufs begin
             if stage === :zipper
@@ -607,6 +680,21 @@ zipper_fill!(fields, north_bcs, locs, grid; periodic_x::Bool = false) =
 # fill_halo_event!(c, kernel!, bcs, indices, loc, arch, grid, args...) with the pair launchers fill_south_and_north_halo! /
 # fill_bottom_and_top_halo!; a `nothing` condition makes the corresponding side a no-op there]
 const OBC = Oceananigans.BoundaryConditions
+# Oceananigans' own halo kernels are KernelAbstractions kernels: they need a backend, and HIPGPU() has none (see the head of this file).
+# Every hand-over to them goes through this check, so that a field this library cannot fill on HIPGPU() ends in an ArgumentError naming
+# the condition -- not in a MethodError from `device(::HIPGPU)` -- while on a backend architecture (ext/TripolarHIPBackendExt.jl) the
+# hand-over proceeds.
+has_ka_backend(arch) = true
+has_ka_backend(::HIPGPU) = false
+has_ka_backend(arch::Distributed) = has_ka_backend(child_architecture(arch))
+needs_oceananigans_kernels(grid, what) = has_ka_backend(architecture(grid)) ||
+    throw(ArgumentError("fill_halo_regions! on a TripolarGrid built on HIPGPU(): $what is Oceananigans' own halo kernel to fill, and HIPGPU() has " *
+                        "no KernelAbstractions backend to launch it on (libtripolar_hip fills the Zipper north side, periodic x and the " *
+                        "latitude-band seams); keep the grid and its fields in the host backend's arrays (ext/TripolarHIPBackendExt.jl) " *
+                        "for fields that carry such conditions"))
+why_not(bcs, indices, zipper_expected) =
+    !full_xy(indices) ? "a field windowed in x or y" :
+    !(is_periodic(bcs.west) && is_periodic(bcs.east)) ? "a non-periodic west / east condition" : "a north condition that is not a Zipper"
 side(c, bs, f) = c isa Tuple ? map(f, bs) : f(bs[1])                          # tupled fill: tuples of conditions; single field: one
 south_only!(c, bs, indices, loc, arch, grid, args...; kwargs...) =
     OBC.fill_halo_event!(c, OBC.fill_south_and_north_halo!, (side(c, bs, b -> fills_south(b.south) ? b.south : nothing), side(c, bs, _ -> nothing)), indices, loc, arch, grid, args...; kwargs...)
@@ -622,10 +710,12 @@ function tripolar_fill!(c, bcs, indices, loc, grid, comm, args...; kwargs...)
     # Oceananigans' own south fill, for a south condition that is a real one: not `nothing` (src/tripolar_grid.jl:148: the reference's own
     # fills) and not the halo-communication condition injected on ranks > 0 (src/distributed_tripolar_grid.jl:171) -- that side is a seam,
     # filled by the RCCL exchange inside the C call; driving Oceananigans' south/north launcher with it would take the MPI path
-    any(b -> fills_south(b.south), bs) && south_only!(c, bs, indices, loc, arch, grid, args...; kwargs...)
+    any(b -> fills_south(b.south), bs) && needs_oceananigans_kernels(grid, "a south boundary condition") &&
+        south_only!(c, bs, indices, loc, arch, grid, args...; kwargs...)
     if all(b -> isnothing(b.bottom) && isnothing(b.top), bs)
         hip_fill!(cs, bs, ls, indices, grid; stage = :all, comm, arch)                      # one C call: fused / merged launch (+ seams)
     else
+        needs_oceananigans_kernels(grid, "a bottom / top boundary condition")
         hip_fill!(cs, bs, ls, indices, grid; stage = :zipper, comm, arch)
         bottom_and_top!(c, bs, indices, loc, arch, grid, args...; kwargs...)
         hip_fill!(cs, bs, ls, indices, grid; stage = :periodic, comm, arch)
@@ -637,12 +727,14 @@ import Oceananigans.BoundaryConditions: fill_halo_regions!
 
 # serial tripolar grid: single field (c::OffsetArray, bcs::FieldBoundaryConditions) and the tupled fill (tuples of both).
 # Fields the C ABI cannot take (non-periodic x, (x, y)-windowed indices, a non-Zipper north side) go to Oceananigans' GENERIC method
-# through `invoke`.  `invoke` needs a signature the generic method is applicable to and this method is not: the generic one is declared on
+# through `invoke` -- on a backend architecture; on HIPGPU() (no KernelAbstractions backend) they end in an ArgumentError that names the
+# condition (needs_oceananigans_kernels).  `invoke` needs a signature the generic method is applicable to and this method is not: the generic one is declared on
 # `c::Union{OffsetArray, NTuple{<:Any, OffsetArray}}` with an untyped grid [recalled], so (typeof(c), ..., AbstractGrid, ...) selects it --
 # `AbstractGrid` is not a subtype of TRG, hence never this method again; an all-`Any` signature would match no method at all.
 function fill_halo_regions!(c::Union{OffsetArray, NTuple{N, OffsetArray} where N}, bcs, indices, loc, grid::TRG, args...; kwargs...)
-    all(b -> hip_fill_applies(b, indices, true), as_tuple(bcs)) ||
-        return invoke(fill_halo_regions!, Tuple{typeof(c), Any, Any, Any, AbstractGrid, Vararg{Any}}, c, bcs, indices, loc, grid, args...; kwargs...)
+    bad = findfirst(b -> !hip_fill_applies(b, indices, true), as_tuple(bcs))
+    isnothing(bad) || (needs_oceananigans_kernels(grid, why_not(as_tuple(bcs)[bad], indices, true)) &&
+        return invoke(fill_halo_regions!, Tuple{typeof(c), Any, Any, Any, AbstractGrid, Vararg{Any}}, c, bcs, indices, loc, grid, args...; kwargs...))
     return tripolar_fill!(c, bcs, indices, loc, grid, nothing, args...; kwargs...)
 end
 
@@ -652,8 +744,9 @@ end
 function fill_halo_regions!(c::Union{OffsetArray, NTuple{N, OffsetArray} where N}, bcs, indices, loc, grid::DTRG, buffers, args...; kwargs...)
     arch = architecture(grid)
     last = arch.local_rank == ranks(arch.partition)[2] - 1
-    all(b -> hip_fill_applies(b, indices, last), as_tuple(bcs)) ||
-        return invoke(fill_halo_regions!, Tuple{typeof(c), Any, Any, Any, DistributedGrid, Any, Vararg{Any}}, c, bcs, indices, loc, grid, buffers, args...; kwargs...)
+    bad = findfirst(b -> !hip_fill_applies(b, indices, last), as_tuple(bcs))
+    isnothing(bad) || (needs_oceananigans_kernels(grid, why_not(as_tuple(bcs)[bad], indices, last)) &&
+        return invoke(fill_halo_regions!, Tuple{typeof(c), Any, Any, Any, DistributedGrid, Any, Vararg{Any}}, c, bcs, indices, loc, grid, buffers, args...; kwargs...))
     return tripolar_fill!(c, bcs, indices, loc, grid, seam_comm(arch), args...; kwargs...)
 end
 
@@ -677,7 +770,7 @@ function halo_exchange_y!(comm::SeamComm, fields, locs, grid; buffers = nothing)
                         (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
                          Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
                         comm.handle, comm.rank, comm.nranks, ptrs, length(fs), bp[1], bp[2], bp[3], bp[4],
-                        Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), current_stream()))
+                        Nx, Ny, Nz, Hx, Hy, Hz, ft_code(FT), stream_for(architecture(grid))))
         end
     end
     return nothing
@@ -694,7 +787,7 @@ function nonorthogonality_angle!(angle, grid::TripolarGrid; immersed = nothing)
         check(ccall((:tpg_nonorthogonality_angle, libtripolar), Cint,
                     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
                     device_pointer(grid.λᶠᶠᵃ), device_pointer(grid.φᶠᶠᵃ), isnothing(immersed) ? C_NULL : device_pointer(immersed),
-                    device_pointer(angle), Nx, Ny, Hx, Hy, ft_code(eltype(grid)), current_stream()))
+                    device_pointer(angle), Nx, Ny, Hx, Hy, ft_code(eltype(grid)), stream_for(architecture(grid))))
     end
     return angle
 end
@@ -708,7 +801,7 @@ function convert_frame!(u_out, v_out, u, v, grid::TripolarGrid; to_native::Bool 
                      Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
                     device_pointer(grid.φᶜᶠᵃ), device_pointer(grid.φᶠᶜᵃ), device_pointer(grid.Δyᶜᶜᵃ), device_pointer(grid.Δxᶜᶜᵃ),
                     device_pointer(u), device_pointer(v), device_pointer(u_out), device_pointer(v_out), to_native ? 1 : 0,
-                    Nx, Ny, Nz, Hx, Hy, Hz, ft_code(eltype(grid)), current_stream()))
+                    Nx, Ny, Nz, Hx, Hy, Hz, ft_code(eltype(grid)), stream_for(architecture(grid))))
     end
     return u_out, v_out
 end

@@ -294,3 +294,57 @@ def test_tables_valid_flag_skips_the_table_kernel_and_changes_nothing(osg, gpu):
         assert not bool(torch.isnan(good[L.ARRAY_NAMES.index("lambda_cc")][H:-H, H:-H]).any())
     p = params(1, Ny, 2)
     assert lib.tpg_build_grid(C.byref(p), L.ptr_table(good), ws.data_ptr(), ws.numel(), None) == -1 and b"unknown flag" in lib.tpg_last_error()
+
+
+def test_grid_hosts_reuse_the_tables_and_a_changed_key_recomputes(osg, oracle, gpu):
+    """The callers of TPG_BUILD_TABLES_VALID (include/tripolar_hip.h): the grid keeps its table workspace, and with_halo (same size, new
+    Hx / Hz: src/with_halo.jl:5-44), reconstruct_global_grid after a band build (src/distributed_tripolar_grid.jl:201-226) and consecutive
+    band builds of one geometry build with the flag -- bit-identical to fresh builds (the oracle); a changed Hy, size, latitude, radius or
+    element type changes the key and recomputes.  A poisoned workspace proves which builds really skipped the table kernel."""
+    import gc
+    from orthogonalsphericalshellgrids.jl_amd import grids
+    size = (120, 60, 2)                                                       # a geometry no other test holds alive
+    g = osg.TripolarGrid(size=size)
+    assert not g.tables_reused and g.workspace.key == grids.table_key(120, 60, 4, torch.float64, -80, 55, osg.R_Earth, g.device)
+    g2 = osg.with_halo((2, 4, 1), g)                                          # new Hx, Hz: same tables
+    assert g2.tables_reused and g2.workspace is g.workspace and compare(g2, oracle.build_grid(size, halo=(2, 4, 1))) == 0
+    g3 = osg.with_halo((4, 3, 4), g)                                          # new Hy: the south-row table has another length -> recomputed
+    assert not g3.tables_reused and g3.workspace is not g.workspace and compare(g3, oracle.build_grid(size, halo=(4, 3, 4))) == 0
+    for kw in (dict(southernmost_latitude=-75), dict(north_poles_latitude=60), dict(radius=1.0)):
+        gk = osg.TripolarGrid(size=size, **kw)
+        assert not gk.tables_reused and compare(gk, oracle.build_grid(size, **kw)) == 0, kw
+    g32 = osg.TripolarGrid(None, torch.float32, size=size)
+    assert not g32.tables_reused
+    gfpl = osg.TripolarGrid(size=size, first_pole_longitude=75)              # first_pole_longitude does not enter the tables
+    assert gfpl.tables_reused and compare(gfpl, oracle.build_grid(size, first_pole_longitude=75)) == 0
+    # consecutive band builds of one geometry, then the globe from the last band
+    glob = oracle.build_grid(size)
+    bands = []
+    for r in range(3):
+        arch = osg.Distributed(osg.GPU(0), osg.Partition(y=3), local_rank=r)
+        b = osg.TripolarGrid(arch, size=size)
+        assert b.tables_reused and b.workspace is g.workspace                 # g is alive: every band finds its tables
+        j0, j1 = b.jrange
+        for name, ref in glob.items():
+            assert np.array_equal(getattr(b, name).cpu().numpy(), ref[j0 - 1:j1 + 8], equal_nan=True), (r, name)
+        bands.append(b)
+    full = osg.reconstruct_global_grid(bands[-1])
+    assert full.tables_reused and compare(full, glob) == 0
+    # the flag really skips the kernel: poison the shared tables, a reusing build goes wrong, a build with another key does not
+    torch.cuda.synchronize()
+    g.workspace.tensor.fill_(0xFF)
+    bad = osg.with_halo((3, 4, 2), g)
+    assert bad.tables_reused and bool(torch.isnan(bad.interior("lambda_cc")).any())
+    ok = osg.with_halo((3, 5, 2), g)
+    assert not ok.tables_reused and compare(ok, oracle.build_grid(size, halo=(3, 5, 2))) == 0
+    # a workspace lives as long as a grid holds it: drop them all and the next build computes its own tables again
+    del g, g2, bad, bands, b, full, gfpl
+    gc.collect()
+    fresh = osg.TripolarGrid(size=size)
+    assert not fresh.tables_reused and compare(fresh, glob) == 0
+    # the tables may have been written on another stream: the reusing build waits for them
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ga = osg.TripolarGrid(size=(240, 120, 1))
+    gb = osg.with_halo((2, 4, 1), ga)                                         # current stream != side
+    assert gb.tables_reused and compare(gb, oracle.build_grid((240, 120, 1), halo=(2, 4, 1))) == 0

@@ -176,13 +176,15 @@ def test_bench_launches_its_own_workers(tmp_path):
     # a failing worker fails the job with its status
     p2 = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, FAIL_RANK="2"))
     assert p2.returncode == 7
-    # and the real thing on a box without a GPU: both workers start, fail on the device assertion (not on a usage message)
+    # and the real thing on a box without a GPU: both workers start and stop at the device-count preflight -- status 7 and ONE readable
+    # line from rank 0 (not a usage message, not a HIP traceback per rank)
     import torch
     if not torch.cuda.is_available():
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         p3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
-        assert p3.returncode != 0 and not p3.stdout.strip()
-        assert "needs a HIP device (rank 0 of 2)" in p3.stderr and "needs a HIP device (rank 1 of 2)" in p3.stderr and "launch N > 1 with" not in p3.stderr
+        assert p3.returncode == 7 and not p3.stdout.strip()
+        diag = [json.loads(l) for l in p3.stderr.splitlines() if l.startswith("{") and "too_few_devices" in l]
+        assert len(diag) == 1 and diag[0]["visible"] == 0 and diag[0]["requested"] == 2 and "launch N > 1 with" not in p3.stderr
 
 
 def test_bench_refuses_a_strong_split_that_does_not_divide():

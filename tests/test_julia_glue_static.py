@@ -231,6 +231,11 @@ def test_fallback_invoke_names_the_generic_method():
     src = open(JL).read()
     sigs = re.findall(r"invoke\(fill_halo_regions!, (Tuple\{.*?\}), c, bcs", src)
     assert len(sigs) == 2
+    # on HIPGPU() (no KernelAbstractions backend) the hand-over must end in an ArgumentError naming the condition, not in a
+    # MethodError: every invoke -- and both of Oceananigans' side launchers -- sits behind needs_oceananigans_kernels
+    assert len(re.findall(r"needs_oceananigans_kernels\(grid, why_not\([^\n]*\) &&\s+return invoke\(fill_halo_regions!", src)) == 2
+    assert "has_ka_backend(::HIPGPU) = false" in src and re.search(r"needs_oceananigans_kernels\(grid, what\) = has_ka_backend\(architecture\(grid\)\) \|\|\s+throw\(ArgumentError\(", src)
+    assert re.search(r'needs_oceananigans_kernels\(grid, "a bottom / top boundary condition"\)\s+hip_fill!', src)
     for sig in sigs:
         inner = split_top(sig[len("Tuple{"):-1])
         assert inner[0] == "typeof(c)" and inner[0] != "Any"
@@ -250,4 +255,72 @@ def test_distributed_fill_batches_and_spares_the_seam_side():
     assert int(re.search(r"const TPG_MAX_FIELDS = (\d+)", src).group(1)) == cmax
     assert "Iterators.partition(group, TPG_MAX_FIELDS)" in src
     assert "fills_south(bc) = !isnothing(bc) && !is_communication(bc)" in src
-    assert "any(b -> fills_south(b.south), bs) && south_only!" in src and "any(b -> !isnothing(b.south), bs)" not in src
+    assert re.search(r"any\(b -> fills_south\(b\.south\), bs\) && needs_oceananigans_kernels\(grid, [^)]*\) &&\s+south_only!", src)
+    assert "any(b -> !isnothing(b.south), bs)" not in src
+
+
+EXT = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "julia", "ext", "TripolarHIPBackendExt.jl")
+
+
+def _code(path):
+    src = open(path).read()
+    return re.sub(r"#.*", "", re.sub(r'"""(?:.|\n)*?"""', '""', src))
+
+
+def test_backend_extension_extracts_pointers_and_streams_only():
+    """the opposite hook of HIPArray -- a grid living in the host backend's own device arrays reaches tpg_* through
+    three methods (device_pointer, device_array, stream_for) defined in a weak-dependency extension.  Statically: the core file still
+    imports no backend and names none; the extension imports the backend, extends exactly the core's hooks, and holds no kernel, no
+    launch and no ccall of its own."""
+    core, ext = _code(JL), _code(EXT)
+    bare = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', core)                       # message strings may name CUDA.jl / the extension; code may not
+    for banned in ("AMDGPU", "ROCArray", "ROCBackend", "CUDA", "KernelAbstractions", "TripolarHIPBackendExt"):
+        assert banned not in bare, banned                                  # comments and messages aside, the core does not know the backend exists
+    assert "stream_for(arch) = current_stream()" in core and "has_ka_backend(arch) = true" in core
+    assert "using AMDGPU: AMDGPU, ROCArray, ROCBackend" in ext and "using TripolarHIP" in ext
+    assert re.search(r"import TripolarHIP: device_pointer, device_array, stream_for, has_ka_backend", ext)
+    defs = re.findall(r"(?m)^(\w+)\((?:[^()]|\([^()]*\))*\) = ", ext)
+    assert sorted(defs) == ["device_array", "device_pointer", "has_ka_backend", "stream_for"], defs
+    assert "device_pointer(a::ROCArray) = Ptr{Cvoid}(pointer(a))" in ext
+    for banned in ("@kernel", "@roc", "launch!", "@index", "ccall", "@cuda", "function "):
+        assert banned not in ext, banned
+    # every stream argument of a tpg_* ccall in the core comes from stream_for(...) (or is the pipelined exchange's own second stream)
+    src = open(JL).read()
+    for m in re.finditer(r"ccall\(\(:(tpg_[a-z0-9_]+),\s*libtripolar\)", src):
+        end = balanced(src, src.index("(", m.start()))
+        args = split_top(src[src.index("(", m.start()) + 1:end - 1])
+        assert not any(v.strip() == "current_stream()" for v in args[3:]), m.group(1)
+
+
+def test_streams_and_tables_are_task_local_or_locked():
+    """no unguarded process-wide dictionary keyed by the current task -- streams and seam buffers live in task_local_storage()
+    (freed with their task: the stream handle has a finalizer calling hipStreamDestroy), the two remaining process-wide tables (seam
+    communicators, table workspaces) are only touched under STATE_LOCK."""
+    code = _code(JL)
+    assert "TASK_STREAMS" not in code and "COMM_STREAMS" not in code and "SEAM_BUFFERS" not in code and "objectid(current_task())" not in code
+    assert "get!(StreamHandle, task_local_storage(), key)" in code and "finalizer(destroy_stream!, h)" in code
+    assert re.search(r"ccall\(\(:hipStreamDestroy, libhip\), Cint, \(Ptr\{Cvoid\},\), h\.ptr\)", code)
+    assert "get!(task_local_storage(), (:tripolar_hip_seam_buffers" in code
+    assert "const STATE_LOCK = ReentrantLock()" in code
+    for table in ("SEAM_COMMS", "GRID_WORKSPACES"):
+        uses = [m.start() for m in re.finditer(table, code)]
+        for u in uses[1:]:                                                # every use after the declaration sits inside a lock(...) expression
+            line_start = code.rfind("\n", 0, u)
+            ctx = code[max(0, code.rfind("lock(", 0, u)):u]
+            assert "lock(" in ctx and (ctx.count("\n") <= 3), (table, code[line_start:u + 40])
+
+
+def test_build_band_sets_the_tables_valid_flag_for_a_live_workspace():
+    """VERDICT r4 next #4 on the Julia side: build_band looks for a live workspace of the same table key, builds with
+    TPG_BUILD_TABLES_VALID when it finds one and ties the workspace to the grid's lambda_cc parent (weak key)."""
+    src = open(JL).read()
+    hdr = open(os.path.join(ROOT, "include", "tripolar_hip.h")).read()
+    flag = int(re.search(r"#define TPG_BUILD_TABLES_VALID (\d+)", hdr).group(1))
+    assert int(re.search(r"const TPG_BUILD_TABLES_VALID = Int32\((\d+)\)", src).group(1)) == flag
+    assert "const GRID_WORKSPACES = WeakKeyDict{Any, TableWorkspace}()" in src
+    assert "reuse ? TPG_BUILD_TABLES_VALID : Int32(0)" in src and "ws  = live_workspace(key, nbytes)" in src
+    # the key holds exactly what the header says the tables depend on
+    key = re.search(r"table_key\(arch, FT, Nλ, Nφ, Hφ, south, npl, radius\) = \((.*)\)", src).group(1)
+    for part in ("child_architecture(arch)", "FT", "Int(Nλ)", "Int(Nφ)", "Int(Hφ)", "Float64(south)", "Float64(npl)", "Float64(radius)"):
+        assert part in key
+    assert "first_pole" not in key and "jstart" not in key and "Hλ" not in key
