@@ -323,6 +323,8 @@ def main():
     ap.add_argument("--loopback-band", type=int, default=3, help="--loopback: which band of the chain this GPU plays (R-1 = the zipper band)")
     ap.add_argument("--deadline", type=float, default=float(os.environ.get("TPG_BENCH_DEADLINE_S", "120")),
                     help="seconds allowed for communicator bring-up and for the first seam exchange (N > 1)")
+    ap.add_argument("--rendezvous-deadline", type=float, default=float(os.environ.get("TPG_BENCH_RENDEZVOUS_DEADLINE_S", "900")),
+                    help="seconds allowed for the process-group rendezvous + RCCL communicator creation (covers a cold `import torch` on every rank)")
     ap.add_argument("--preroll", type=int, default=-1,
                     help="plain tpg_build_grid calls before the warm-up steps (the declared clock pre-roll); default 64 per 1800 rows of band, 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -347,6 +349,7 @@ def main():
     sys.stdout.flush()
     os.dup2(2, 1)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC only on these hosts (RCCL's P2P set-up); read when HSA initialises
     import torch
     import torch.distributed as dist
     if not (os.path.exists(LIB) and os.path.exists(os.path.join(ROOT, "tools", "libtripolar_hip_test.so"))):
@@ -405,7 +408,10 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dog.info["transport"] = "librccl via tpg_comm_init_rank"
-            dog.arm("torch.distributed init_process_group(nccl)")
+            # the rendezvous waits for the SLOWEST rank's `import torch`, and on a fresh node the first import pages the image in (1-2 minutes,
+            # N processes at once): this phase gets its own, longer limit so that a cold start is not mistaken for a stalled exchange
+            dog.seconds = max(args.deadline, args.rendezvous_deadline)
+            dog.arm("torch.distributed init_process_group(nccl): rendezvous with the other ranks")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             # The exchange itself is librccl through the C ABI (tpg_halo_exchange_y).  RcclComm.from_torch first lets every rank report
             # whether it can bind librccl and agrees on that BEFORE the collective ncclCommInitRank; should the communicator still fail
@@ -420,6 +426,7 @@ def main():
             if int(ok.item()) == 0 and comm is not None:
                 comm.destroy(); comm = None
             dog.disarm()
+            dog.seconds = args.deadline
             if comm is None:
                 if loopback:
                     raise SystemExit(f"--loopback needs the C ABI's RCCL communicator: {comm_error}")

@@ -23,7 +23,10 @@
 constexpr int NX = 3600, NY = 1800, NZ = 75, H = 4;
 constexpr int SX = NX + 2 * H, SY = NY + 2 * H, LEV = NZ + 2 * H;
 constexpr long long PLANE = (long long)SX * SY;
-constexpr int NF = 4;
+#ifndef FB_NF
+#define FB_NF 4                                      // fields per launch (run.sh timeline builds 4, 8 and 16)
+#endif
+constexpr int NF = FB_NF;
 constexpr int NCH = NX / 2;                       // 16-B chunks per row
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -531,6 +534,14 @@ static void timeline(const char* name, bool copy, int mode /*0 dirty 1 clean 2 w
         for (long long w = 0; w < nw; ++w) if (h[w * 4 + 1]) lat.push_back((double)(h[w * 4 + 1] - h[w * 4]) * 0.01);
         std::sort(lat.begin(), lat.end());
         printf("   load latency   p0 %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  p100 %6.2f us\n", lat[0], lat[lat.size() / 10], lat[lat.size() / 2], lat[lat.size() * 9 / 10], lat.back());
+        // the launch as ramp + saturated window + drain: between the 5 % and the 95 % quantile of "stores acked" 90 % of the bytes complete
+        {
+            auto Q = [&](int q, double p) { return s[q][(size_t)(p * (s[q].size() - 1))]; };
+            const double bytes = (2 * 17.28e6 + 2 * 19.44e6) * NF / 4;
+            const double t5 = Q(3, .05), t95 = Q(3, .95), win = t95 - t5;
+            printf("   model          first 5 %% of the waves done at %.2f us (ramp), 5..95 %% in %.2f us = %.2f TB/s inside the window, last wave %.2f us after the 95 %% mark, "
+                   "kernel - last ack %.2f us\n", t5, win, 0.9 * bytes / win / 1e6, Q(3, 1.0) - t95, ms * 1e3 - Q(3, 1.0));
+        }
     }
     CHECK(hipFree(d));
     fflush(stdout);
@@ -541,7 +552,8 @@ int main(int argc, char** argv)
     const std::string exp = argc > 1 ? argv[1] : "all";
     const int rounds = argc > 2 ? atoi(argv[2]) : 10;
     const size_t fbytes = (size_t)PLANE * LEV * 8;
-    const int xl[NF] = { 0, 1, 0, 1 }, yl[NF] = { 0, 0, 1, 1 }, sg[NF] = { 1, -1, -1, 1 };
+    int xl[NF], yl[NF], sg[NF];                     // locations cycle c (CC,+1), u (FC,-1), v (CF,-1), zeta (FF,+1)
+    for (int f = 0; f < NF; ++f) { xl[f] = f & 1; yl[f] = (f >> 1) & 1; sg[f] = ((f & 3) == 0 || (f & 3) == 3) ? 1 : -1; }
     for (int f = 0; f < NF; ++f) {
         CHECK(hipMalloc(&g_ft.p[f], fbytes));
         hipLaunchKernelGGL(k_init, dim3(8192), dim3(256), 0, 0, g_ft.p[f], (long long)(fbytes / 8), 1.0 + f);
@@ -550,7 +562,7 @@ int main(int argc, char** argv)
     CHECK(hipMalloc(&g_flush, FLUSH_N * 8));
     CHECK(hipMemset(g_flush, 0, FLUSH_N * 8));
     CHECK(hipEventCreate(&ev0)); CHECK(hipEventCreate(&ev1));
-    const double zbytes = 2 * 17.28e6 + 2 * 19.44e6;
+    const double zbytes = (2 * 17.28e6 + 2 * 19.44e6) * NF / 4;
     const long long nrows = (long long)SY * LEV;
     const double pbytes = (double)nrows * NF * 2 * H * 2 * 8;
 

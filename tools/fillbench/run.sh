@@ -10,7 +10,14 @@ BIN=$REPO/tools/fillbench/fillbench
 OUT=$REPO/gpurun_out/fillbench_$EXP; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 if [ "$EXP" = timeline ]; then
-  "$BIN" timeline > "$OUT/log.txt" 2>&1; echo "rc=$?"; cat "$OUT/log.txt"; exit 0
+  # per-wave stamps inside the fold for 4 (the headline), 8 and 16 fields per launch: what is fixed (ramp, drain) and what scales
+  "$BIN" timeline > "$OUT/log.txt" 2>&1; echo "rc=$?"
+  for NFB in 8 16; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFB_NF=$NFB -o "$BIN.nf$NFB" "$REPO/tools/fillbench/fillbench.hip" || exit 1
+    echo "==== $NFB fields per launch ====" >> "$OUT/log.txt"
+    "$BIN.nf$NFB" timeline >> "$OUT/log.txt" 2>&1; echo "nf$NFB rc=$?"
+  done
+  cat "$OUT/log.txt"; exit 0
 fi
 if [ "$3" = pmc ]; then    # separate counter passes (kernel-trace only beside --pmc): bytes fetched / written per launch, by kernel
   for CNT in FETCH_SIZE WRITE_SIZE; do

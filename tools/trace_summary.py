@@ -6,7 +6,9 @@ neighbours in the trace:
   step       k_tables, k_cells_tile, k_halos, k_fill_merged                      (the timed steps and the instrumented pass)
   fold pass  k_tables, k_cells_tile, k_halos, k_zipper_cols, k_periodic_x_vec    (the pass behind `roofline_fold`)
 A `step` whose kernels follow each other within 5 us is a TIMED step (the instrumented pass has stream markers between
-its phases, ~10 us each); only those enter the `timed_step` rows, which are the figures to compare with `roofline`.
+its phases, ~10 us each); only those enter the `timed_step` rows, which are the figures to compare with `roofline`.  Marker-free
+steps that come AFTER the fold pass are the K cold-onset steps of round 5 (`ms_per_step_cold_onset`: started right after 100 passes
+over 1 GiB): they get their own `cold_onset_step` rows.
 usage: tools/trace_summary.py <bench_kernel_trace.csv> [out.csv]"""
 import csv
 import re
@@ -28,23 +30,25 @@ def main():
     t0 = [int(r["Start_Timestamp"]) for r in rows]
     t1 = [int(r["End_Timestamp"]) for r in rows]
     dur = [(b - a) / 1e3 for a, b in zip(t0, t1)]
-    acc = {"timed_step": {k: [] for k in STEP}, "instrumented_step": {k: [] for k in STEP}, "fold_pass": {k: [] for k in FOLD}}
-    i = 0
+    acc = {"timed_step": {k: [] for k in STEP}, "instrumented_step": {k: [] for k in STEP}, "fold_pass": {k: [] for k in FOLD},
+           "cold_onset_step": {k: [] for k in STEP}}
+    i, seen_fold = 0, False
     while i < len(rows):
         if names[i:i + len(FOLD)] == FOLD and "true>" not in rows[i + 3]["Kernel_Name"].split("k_zipper_cols")[1][:24]:
             for k, d in zip(FOLD, dur[i:i + len(FOLD)]):
                 acc["fold_pass"][k].append(d)
             i += len(FOLD)
+            seen_fold = True
         elif names[i:i + len(STEP)] == STEP:
             gaps = [(t0[i + j + 1] - t1[i + j]) / 1e3 for j in range(len(STEP) - 1)]
-            kind = "timed_step" if max(gaps) < 5.0 else "instrumented_step"
+            kind = ("cold_onset_step" if seen_fold else "timed_step") if max(gaps) < 5.0 else "instrumented_step"
             for k, d in zip(STEP, dur[i:i + len(STEP)]):
                 acc[kind][k].append(d)
             i += len(STEP)
         else:
             i += 1
     out = [("sequence", "kernel", "launches", "avg_us", "median_us", "min_us", "max_us")]
-    for kind, order in (("timed_step", STEP), ("instrumented_step", STEP), ("fold_pass", FOLD)):
+    for kind, order in (("timed_step", STEP), ("instrumented_step", STEP), ("fold_pass", FOLD), ("cold_onset_step", STEP)):
         for k in order:
             d = acc[kind][k]
             if d:
