@@ -329,6 +329,7 @@ def main():
                     help="plain tpg_build_grid calls before the warm-up steps (the declared clock pre-roll); default 64 per 1800 rows of band, 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fill-step", action="store_true", help="skip the config-5 (1/24 deg x 100 levels) fill_step measurement")
+    ap.add_argument("--no-cold-onset", action="store_true", help="skip the K cold-onset steps (profiling passes: keeps the 100 streaming launches out of the trace)")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary measurements (cache states, copy ceiling, Float32, config 2, geometry)")
     args = ap.parse_args()
 
@@ -799,7 +800,7 @@ def main():
     # ---- the step right after HBM-bound work: K steps, no pre-roll, no warm-up, after >= 50 ms of streaming traffic ------------------------
     # (what the FIRST builds of a caller cost: the cell kernel's onset transient included.  Untimed region, N = 1 only.)
     cold_onset = None
-    if not chain:
+    if not chain and not args.no_cold_onset:
         flush = torch.zeros(1 << 27, dtype=torch.float64, device=dev)          # 1 GiB
         torch.cuda.synchronize()
         h0, h1 = ev(), ev()

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TPG_VERSION 400 /* 0.4.0 */
+#define TPG_VERSION 500 /* 0.5.0 */
 
 enum tpg_status {
     TPG_OK = 0,
@@ -88,8 +88,10 @@ typedef struct tpg_params {
  * southernmost_latitude, north_poles_latitude and radius were the same (jstart / jend, Hx, Hz, Nz, first_pole_longitude may
  * differ): the table kernel (~9 us: one double-double asinh -> sinh, cosh chain per latitude row) is skipped.  For hosts that
  * build several grids of one geometry -- with_halo (src/with_halo.jl:5-44: same size, new halo in x or z),
- * reconstruct_global_grid after a band build, repeated band builds.  The caller vouches for the workspace contents; results
- * are identical to a build without the flag.  bench.py's timed steps never set it. */
+ * reconstruct_global_grid after a band build, repeated band builds: the Python host (grids.py: TableWorkspace kept with the
+ * grid) and the Julia glue (build_band) set it on exactly these paths and allocate a fresh workspace whenever the key differs.
+ * The caller vouches for the workspace contents; results are identical to a build without the flag.  bench.py's timed steps
+ * never set it. */
 #define TPG_BUILD_TABLES_VALID 1
 
 int tpg_version(void);

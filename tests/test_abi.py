@@ -61,7 +61,7 @@ def test_product_library_exports_exactly_the_header(osg):
 
 def test_version_and_status_strings(osg):
     lib = osg._lib.lib()
-    assert lib.tpg_version() == 400
+    assert lib.tpg_version() == 500
     assert b"even" in lib.tpg_status_string(-2)
     assert lib.tpg_status_string(0) == b"ok"
 

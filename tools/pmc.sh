@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name counters...
   local name=$1; shift
   local OUT=$REPO/gpurun_out/pmc_${TAG}_$name; rm -rf "$OUT"; mkdir -p "$OUT"
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -o p -- python3 "$REPO/bench.py" --no-cpu-baseline --no-aux --no-fill-step --steps 5 --warmup 1 > "$OUT/bench.json" 2> "$OUT/stderr.txt"
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT" -o p -- python3 "$REPO/bench.py" --no-cpu-baseline --no-aux --no-fill-step --no-cold-onset --preroll 4 --steps 5 --warmup 1 > "$OUT/bench.json" 2> "$OUT/stderr.txt"
   echo "== $name rc=$?"
 }
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
