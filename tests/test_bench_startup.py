@@ -1,7 +1,7 @@
 """bench.py's start-up at BASELINE config 4's own N, without a device: the launcher, the rendezvous, the band layout and the seam
 pairing of `python bench.py --gpus 8` (src/distributed_tripolar_grid.jl:36-49,75,143-147; examples/distributed_bickley_jet.jl:8-25),
 and the one-line diagnostic of a node that shows fewer devices than ranks.  The 8-rank run WITH kernels cannot be rehearsed on a
-one-GPU box (its process guard allows 6 processes on the card: tests/test_gpu_bench_contract.py runs N = 5 beside the test process);
+one-GPU box (its process guard allows 6 processes on the card: tests/test_gpu_bench_contract.py runs N <= 4 beside the test process, N = 6 was run by hand);
 these tests run here."""
 import json
 import os

@@ -136,28 +136,16 @@ def test_bench_two_ranks_rehearsal(gpu):
 def test_bench_four_ranks_rehearsal_interior_ranks_verify_both_seams(gpu):
     """`python bench.py --gpus 4` (self-started workers, gloo rehearsal on this one GPU): the two interior ranks carry two seams each, with
     different neighbours on either side, and every rank's bit-exact seam verification must pass (each rebuilds BOTH neighbours' rows)."""
-    d = _two_rank_bench([], ranks=4)
+    d = _two_rank_bench([], ranks=4)              # 4 workers + this test process = 5 holders of the card; the box's process guard allows 6, and
+    # the suite keeps one in reserve (a 6-rank rehearsal from inside pytest was killed at 7 holders in round 5): N = 5, 6 are run by hand
+    # outside pytest (profiles/r05/rehearsal_6ranks.json), config 4's own N = 8 start-up device-free in tests/test_bench_startup.py
     assert d["n_gpus"] == 4 and d["config"]["rows_per_rank"] == 450 and d["config"]["parallelism"] == "latitude-bands x4"
+    assert d["clock_preroll"]["builds"] == 64 * 4 and d["ms_per_step_cold_onset"] is None
     pr = d["per_rank"]
     assert [r["rows"] for r in pr] == [[1, 450], [451, 900], [901, 1350], [1351, 1800]]
     assert [r["seams"] for r in pr] == [1, 2, 2, 1] and [r["zipper"] for r in pr] == [False, False, False, True]
     assert all(r["seams_bit_exact"] for r in pr) and "bit for bit" in d["seam_check"]
     assert abs(d["value"] - 3600 * 1800 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
-
-
-def test_bench_five_ranks_rehearsal_the_most_one_card_allows(gpu):
-    """`python bench.py --gpus 5` (self-started workers, gloo rehearsal): the box's process guard allows 6 processes on the card and this
-    test process is one of them, so five ranks is the longest chain rehearsed WITH kernels from inside the suite -- three interior ranks
-    with two seams each, 360 rows per rank.  BASELINE config 4's own N = 8 start-up (225 rows, six two-seam ranks) is
-    tests/test_bench_startup.py (device-free) and its band geometry with the real kernels is tests/test_gpu_distributed.py (8 emulated
-    ranks in one process) and the --loopback runs below (bands 3 and 7 of 8 over RCCL)."""
-    d = _two_rank_bench([], ranks=5)
-    assert d["n_gpus"] == 5 and d["config"]["rows_per_rank"] == 360 and d["config"]["parallelism"] == "latitude-bands x5"
-    pr = d["per_rank"]
-    assert [r["rows"] for r in pr] == [[360 * r + 1, 360 * r + 360] for r in range(5)]
-    assert [r["seams"] for r in pr] == [1, 2, 2, 2, 1] and [r["zipper"] for r in pr] == [False] * 4 + [True]
-    assert all(r["seams_bit_exact"] for r in pr)
-    assert d["clock_preroll"]["builds"] == 64 * 5 and d["ms_per_step_cold_onset"] is None
 
 
 def test_bench_stalled_teardown_is_reported(gpu):
