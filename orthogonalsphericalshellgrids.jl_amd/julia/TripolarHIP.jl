@@ -236,8 +236,10 @@ current_stream() = USE_DEFAULT_STREAM[] ? C_NULL : task_stream(:tripolar_hip_str
 synchronize_stream(s = current_stream()) = hipcheck(ccall((:hipStreamSynchronize, libhip), Cint, (Ptr{Cvoid},), s))
 # the stream this library enqueues on for arrays of `arch`: this file's own task stream for HIPGPU(); a backend extension returns its
 # backend's current stream handle, so that the `tpg_*` kernels order themselves with the host model's own kernels
+serial_arch(arch) = arch                                        # the per-process architecture under a Distributed wrapper
+serial_arch(arch::Distributed) = child_architecture(arch)
 stream_for(arch) = current_stream()
-stream_for(arch::Distributed) = stream_for(child_architecture(arch))
+stream_for(arch::Distributed) = stream_for(serial_arch(arch))
 
 # process-wide tables of this file (seam communicators, table workspaces) are guarded by one lock: fills may come from several threads
 const STATE_LOCK = ReentrantLock()
@@ -285,7 +287,7 @@ mutable struct TableWorkspace
     stream::Ptr{Cvoid}             # the stream the table kernel ran on
 end
 const GRID_WORKSPACES = WeakKeyDict{Any, TableWorkspace}()
-table_key(arch, FT, Nλ, Nφ, Hφ, south, npl, radius) = (child_architecture(arch), FT, Int(Nλ), Int(Nφ), Int(Hφ), Float64(south), Float64(npl), Float64(radius))
+table_key(arch, FT, Nλ, Nφ, Hφ, south, npl, radius) = (serial_arch(arch), FT, Int(Nλ), Int(Nφ), Int(Hφ), Float64(south), Float64(npl), Float64(radius))
 function live_workspace(key, nbytes)
     lock(STATE_LOCK) do
         for w in values(GRID_WORKSPACES)
@@ -686,7 +688,7 @@ const OBC = Oceananigans.BoundaryConditions
 # hand-over proceeds.
 has_ka_backend(arch) = true
 has_ka_backend(::HIPGPU) = false
-has_ka_backend(arch::Distributed) = has_ka_backend(child_architecture(arch))
+has_ka_backend(arch::Distributed) = has_ka_backend(serial_arch(arch))
 needs_oceananigans_kernels(grid, what) = has_ka_backend(architecture(grid)) ||
     throw(ArgumentError("fill_halo_regions! on a TripolarGrid built on HIPGPU(): $what is Oceananigans' own halo kernel to fill, and HIPGPU() has " *
                         "no KernelAbstractions backend to launch it on (libtripolar_hip fills the Zipper north side, periodic x and the " *

@@ -321,6 +321,6 @@ def test_build_band_sets_the_tables_valid_flag_for_a_live_workspace():
     assert "reuse ? TPG_BUILD_TABLES_VALID : Int32(0)" in src and "ws  = live_workspace(key, nbytes)" in src
     # the key holds exactly what the header says the tables depend on
     key = re.search(r"table_key\(arch, FT, Nλ, Nφ, Hφ, south, npl, radius\) = \((.*)\)", src).group(1)
-    for part in ("child_architecture(arch)", "FT", "Int(Nλ)", "Int(Nφ)", "Int(Hφ)", "Float64(south)", "Float64(npl)", "Float64(radius)"):
+    for part in ("serial_arch(arch)", "FT", "Int(Nλ)", "Int(Nφ)", "Int(Hφ)", "Float64(south)", "Float64(npl)", "Float64(radius)"):
         assert part in key
     assert "first_pole" not in key and "jstart" not in key and "Hλ" not in key
