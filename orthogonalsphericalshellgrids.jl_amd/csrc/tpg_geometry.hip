@@ -113,7 +113,10 @@ __global__ __launch_bounds__(256) void k_convert_frame(const T* __restrict__ phi
 }
 
 // 16-byte form: a thread owns W adjacent columns (2 doubles / 4 floats) of ZCH consecutive levels -- W sets of direction
-// cosines, 16-B streaming loads and stores (Nx and Hx multiples of W, 16-B aligned arrays; otherwise the scalar kernel)
+// cosines, 16-B streaming loads and stores (Nx and Hx multiples of W, 16-B aligned arrays; otherwise the scalar kernel).
+// Threads are numbered over (chunk, row) jointly: a row of 3600 columns is 1800 chunks = 7.03 blocks of 256, and a grid with one block
+// row per grid row would leave every eighth block with 8 live lanes (round 5, tools/frame_ab.py: -3 .. -5 % with the flat numbering;
+// more loads in flight, plain loads, 8 / 32 / all levels per thread: all within +-2 %).
 template <typename T, int W>
 __global__ __launch_bounds__(256) void k_convert_frame_vec(const T* __restrict__ phi_cf, const T* __restrict__ phi_fc,
                                                            const T* __restrict__ dy_cc, const T* __restrict__ dx_cc,
@@ -121,9 +124,11 @@ __global__ __launch_bounds__(256) void k_convert_frame_vec(const T* __restrict__
                                                            T* __restrict__ uo, T* __restrict__ vo, FrameArgs a)
 {
     typedef T vec_t __attribute__((ext_vector_type(W)));
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * W + 1;          // first of the W columns
-    const int j = blockIdx.y + 1;
-    if (i > a.Nx) return;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = a.Nx / W;
+    if (t >= (long long)per_row * a.Ny) return;
+    const int j = (int)(t / per_row) + 1;
+    const int i = (int)(t - (long long)(j - 1) * per_row) * W + 1;          // first of the W columns
     const long long c2 = (long long)(i + a.Hx - 1) + (long long)a.sx * (j + a.Hy - 1);
     const T d2r = (T)kDeg2Rad;
     T d1[W], d2[W];
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void k_convert_frame_vec(const T* __restrict__
         const T U = root<T>(ut * ut + vt * vt);
         d1[e] = ut / U; d2[e] = vt / U;
     }
-    const int k0 = blockIdx.z * ZCH, k1 = k0 + ZCH < a.Nz ? k0 + ZCH : a.Nz;
+    const int k0 = blockIdx.y * ZCH, k1 = k0 + ZCH < a.Nz ? k0 + ZCH : a.Nz;
     long long c3 = c2 + a.plane * (k0 + a.Hz);
     int k = k0;
     for (; k + 4 <= k1; k += 4, c3 += 4 * a.plane) {
@@ -204,7 +209,7 @@ int tpg_convert_frame(const void* phi_cf, const void* phi_fc, const void* dy_cc,
     bool vec = (Nx % W == 0) && (Hx % W == 0);
     for (const void* q : { u, v, (const void*)u_out, (const void*)v_out }) vec = vec && ((uintptr_t)q % 16) == 0;
     if (vec) {
-        dim3 grid((Nx / W + 255) / 256, Ny, (Nz + ZCH - 1) / ZCH);
+        dim3 grid((unsigned)(((long long)(Nx / W) * Ny + 255) / 256), (Nz + ZCH - 1) / ZCH);      // (chunk, row) jointly; level groups on y
         if (ft == TPG_F64)
             hipLaunchKernelGGL((k_convert_frame_vec<double, 2>), grid, dim3(256), 0, s, static_cast<const double*>(phi_cf), static_cast<const double*>(phi_fc),
                                static_cast<const double*>(dy_cc), static_cast<const double*>(dx_cc), static_cast<const double*>(u),
