@@ -561,7 +561,8 @@ int main(int argc, char** argv)
     }
     CHECK(hipMalloc(&g_flush, FLUSH_N * 8));
     CHECK(hipMemset(g_flush, 0, FLUSH_N * 8));
-    CHECK(hipEventCreate(&ev0)); CHECK(hipEventCreate(&ev1));
+    // timing-only events, as the product's tpg_event_create: a default event makes the launch end with a system-scope release (+ ~2 us)
+    CHECK(hipEventCreateWithFlags(&ev0, hipEventDisableSystemFence)); CHECK(hipEventCreateWithFlags(&ev1, hipEventDisableSystemFence));
     const double zbytes = (2 * 17.28e6 + 2 * 19.44e6) * NF / 4;
     const long long nrows = (long long)SY * LEV;
     const double pbytes = (double)nrows * NF * 2 * H * 2 * 8;
