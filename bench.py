@@ -377,7 +377,12 @@ def main():
     L = chain_layout(world, rank, args.scaling, (args.loopback_bands, args.loopback_band) if loopback else None)
     bands, band, chain, strong = L["bands"], L["band"], L["chain"], L["strong"]
     south_peer, north_peer, north_is_zipper = L["south_peer"], L["north_peer"], L["north_is_zipper"]   # RCCL peers; -1 = no seam on that side
-    rehearse = os.environ.get("TPG_BENCH_REHEARSE") == "1" and not loopback
+    # TPG_BENCH_REHEARSE (one-GPU boxes; never set by the driver): "1" = every rank on cuda:0, seams host-staged over gloo through the FALLBACK
+    # transport (comm is None); "shim" = the same, but the PRODUCTION branch (comm is not None: the C ABI's one-call distributed fill in all
+    # three exchange forms) runs, its librccl entry points served by the test double tools/nccl_shim (shared-memory mailboxes between the
+    # processes) behind the TEST library; "plan" = start-up only, no device (plan_rehearsal above).  Timings of such runs mean nothing.
+    shim = os.environ.get("TPG_BENCH_REHEARSE") == "shim" and not loopback
+    rehearse = (os.environ.get("TPG_BENCH_REHEARSE") == "1" or shim) and not loopback
     # A node that shows fewer devices than ranks (a short node, a narrowed HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES) must end the job with
     # one readable line, not with N raw "invalid device ordinal" tracebacks.  device_count() does not initialise the GPU.
     visible = int(os.environ["TPG_BENCH_TEST_DEVICE_COUNT"]) if "TPG_BENCH_TEST_DEVICE_COUNT" in os.environ else torch.cuda.device_count()
@@ -386,7 +391,7 @@ def main():
             print(json.dumps({"event": "too_few_devices", "visible": visible, "requested": world, "rank": rank, "local_rank": local_rank,
                               "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES"),
                               "hint": "bench.py runs one process per GPU: --gpus N needs N visible HIP devices on this node "
-                                      "(a one-GPU rehearsal of the N-rank code path: TPG_BENCH_REHEARSE=1, N <= 6; its start-up only, any N: TPG_BENCH_REHEARSE=plan)"}), file=sys.stderr, flush=True)
+                                      "(a one-GPU rehearsal of the N-rank code path: TPG_BENCH_REHEARSE=1 or =shim, N <= 6; its start-up only, any N: TPG_BENCH_REHEARSE=plan)"}), file=sys.stderr, flush=True)
         sys.exit(7)
     assert torch.cuda.is_available(), f"bench.py needs a HIP device (rank {rank} of {world})"
     if rehearse:
@@ -407,6 +412,15 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(free_port()))
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+            if shim:
+                # the package's and this file's C calls go through the TEST library (same objects as the product + knobs), whose exchange
+                # binds the test double instead of librccl; TPG_RCCL_LIBRARY is read at the library's first call, i.e. below
+                os.environ.setdefault("TPG_RCCL_LIBRARY", os.path.join(ROOT, "tools", "nccl_shim", "libnccl_shim.so"))
+                _lib._lib = testlib.lib()
+                dog.info["transport"] = "TEST DOUBLE of librccl (tools/nccl_shim) via tpg_comm_init_rank"
+                dog.arm("RcclComm.from_torch over the nccl_shim test double")
+                comm = osg.RcclComm.from_torch()
+                dog.disarm()
         else:
             dog.info["transport"] = "librccl via tpg_comm_init_rank"
             # the rendezvous waits for the SLOWEST rank's `import torch`, and on a fresh node the first import pages the image in (1-2 minutes,
@@ -861,7 +875,9 @@ def main():
         if chain:
             seam_bytes = 4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8
             hidden = max(0.0, min(1.0, (t_build + t_fillx - ms_per_step) / max(1e-9, min(t_build, t_fillx))))
-            transport_name = ("gloo, host-staged (rehearsal: timings meaningless)" if rehearse
+            transport_name = ("tpg_fill_halo_regions_distributed(_pipelined)_peers -> TEST DOUBLE of librccl (tools/nccl_shim: shared-memory mailboxes "
+                              "between the processes of one GPU; rehearsal of the production branch: timings meaningless)" if shim
+                              else "gloo, host-staged (rehearsal: timings meaningless)" if rehearse
                               else ("tpg_fill_halo_regions_distributed(_pipelined)_peers -> librccl ncclSend/ncclRecv groups, packed messages"
                                     if comm is not None else "torch.distributed batch_isend_irecv (nccl = RCCL), packed messages [fallback]"))
             line.update({

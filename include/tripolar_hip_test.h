@@ -16,6 +16,9 @@
  *    TPG_EXCHANGE_IN_CAPTURE  1 lets tpg_halo_exchange_y through on a capturing stream (tools/rccl_capture_probe.py only)
  *    TPG_EXCHANGE_FAIL_STAGE  k >= 0: tpg_halo_exchange_y_pipelined* returns an injected TPG_ERR_RCCL right after the RCCL group of
  *                             stage k has been enqueued on comm_stream (error-path post-condition test); -1 / unset: off
+ *    TPG_RCCL_LIBRARY         path of the library to bind INSTEAD of librccl: the test double tools/nccl_shim/libnccl_shim.so (shared-memory
+ *                             mailboxes between processes that share one GPU), so that the exchange entry points run with more than one rank
+ *                             on a one-GPU box; read once per process, before the first exchange call
  */
 #ifndef TRIPOLAR_HIP_TEST_H
 #define TRIPOLAR_HIP_TEST_H

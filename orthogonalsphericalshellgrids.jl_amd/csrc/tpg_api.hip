@@ -39,6 +39,8 @@ static const Config* read_config()
     c->fill_merged = env_int("TPG_FILL_MERGED", -1);
     c->exchange_in_capture = env_int("TPG_EXCHANGE_IN_CAPTURE", 0) != 0;
     c->exchange_fail_stage = env_int("TPG_EXCHANGE_FAIL_STAGE", -1);
+    const char* lib = getenv("TPG_RCCL_LIBRARY");
+    c->rccl_library = (lib && *lib) ? strdup(lib) : nullptr;
     return c;
 }
 
@@ -56,7 +58,7 @@ const Config& config()
 // the product library has no knobs: one constant record, no environment access
 const Config& config()
 {
-    static const Config k{ 3, true, 3, -1, -1, false, -1 };
+    static const Config k{ 3, true, 3, -1, -1, false, -1, nullptr };
     return k;
 }
 #endif

@@ -56,6 +56,9 @@ struct Config {
     int exchange_fail_stage;  // TPG_EXCHANGE_FAIL_STAGE  -1 (default, and always in the product): off; k >= 0: the pipelined seam exchange reports
                               //                          an injected failure right after the RCCL group of stage k went onto comm_stream
                               //                          (tests/test_gpu_exchange.py: the error-path post-condition)
+    const char* rccl_library; // TPG_RCCL_LIBRARY  nullptr (default, and always in the product): bind librccl by its fixed names; a path: bind THAT
+                              //                   library instead -- the test double tools/nccl_shim/libnccl_shim.so, so that the exchange code runs
+                              //                   between several real processes on a one-GPU box (RCCL refuses two ranks on one device)
 };
 const Config& config();
 

@@ -50,9 +50,11 @@ std::once_flag g_rccl_once;
 void load_rccl()
 {
     const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+    const char* forced = tpg::config().rccl_library;             // test library only (TPG_RCCL_LIBRARY): the test double of tools/nccl_shim
+    if (forced) g_rccl.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
     for (const char* n : names) {
+        if (g_rccl.handle || forced) break;
         g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (g_rccl.handle) break;
     }
     if (!g_rccl.handle) { snprintf(g_rccl.why, sizeof g_rccl.why, "librccl not found: %s", dlerror()); return; }
     bool ok = true;

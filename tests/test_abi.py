@@ -190,3 +190,13 @@ def test_only_the_checker_sites_load_the_oracle():
         top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))
                and ("oracle" in (getattr(n, "module", None) or "") or any("oracle" in a.name for a in n.names))]
         assert not top, name
+
+
+def test_product_library_does_not_know_the_test_double():
+    """the knob that selects the double lives in the test library only"""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prod = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "libtripolar_hip.so")
+    strings = subprocess.run(["strings", prod], capture_output=True, text=True).stdout
+    assert "TPG_RCCL_LIBRARY" not in strings and "nccl_shim" not in strings
+    assert "TPG_RCCL_LIBRARY" in subprocess.run(["strings", os.path.join(ROOT, "tools", "libtripolar_hip_test.so")], capture_output=True, text=True).stdout

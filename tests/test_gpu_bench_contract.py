@@ -148,6 +148,31 @@ def test_bench_four_ranks_rehearsal_interior_ranks_verify_both_seams(gpu):
     assert abs(d["value"] - 3600 * 1800 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 
+def test_bench_production_branch_between_real_processes_over_the_test_double(gpu):
+    """`TPG_BENCH_REHEARSE=shim python bench.py --gpus 4`: the branch the driver's multi-GPU run takes (`comm is not None`: RcclComm.from_torch at
+    world 4, seam buffers, tpg_fill_halo_regions_distributed_peers and both pipelined forms at first contact, the pre-pass that picks a form by
+    max-over-ranks time, the side / comm streams, per-form instrumented passes) -- between four real processes with different neighbours on
+    either side, its librccl entry points served by the test double tools/nccl_shim behind the test library.  Until round 5 this branch had only
+    ever run at world size 1 (--loopback); the gloo rehearsals above take the FALLBACK transport.  Every rank verifies its seams bit for bit."""
+    env = dict(os.environ, TPG_BENCH_REHEARSE="shim", MASTER_ADDR="127.0.0.1", TPG_SHIM_DEADLINE_S="60")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TPG_RCCL_LIBRARY"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--preroll", "8"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["rows_per_rank"] == 450 and "TEST DOUBLE of librccl" in d["exchange_transport"]
+    forms = {"monolithic", "pipelined_1", "pipelined_2"}
+    assert set(d["exchange_prepass_fill_ms"]) == forms and d["exchange_form"] in forms                 # all three forms ran on every rank
+    assert d["exchange_ms_monolithic"] > 0 and d["exchange_ms_pipelined_1"] > 0 and d["exchange_ms_pipelined_2"] > 0
+    pr = d["per_rank"]
+    assert [r["seams"] for r in pr] == [1, 2, 2, 1] and [r["zipper"] for r in pr] == [False, False, False, True]
+    assert all(r["seams_bit_exact"] for r in pr) and all(set(r["exchange_ms_by_form"]) == forms for r in pr)
+    assert d["roofline"]["launch_ms"] > 0                                                              # the zipper band's merged fold ran (rank 3)
+
+
 def test_bench_stalled_teardown_is_reported(gpu):
     """A communicator / process-group shutdown that never returns (TPG_BENCH_TEST_STALL_TEARDOWN on rank 1 of a two-rank rehearsal, 3 s
     limit): the contract line is already out, the job still exits 0 -- and rank 1 says on stderr which call it was stuck in."""
