@@ -87,16 +87,17 @@ def _worker(rank, world, port, out):
             for name, call, local_fill in forms:
                 if name == "pack-free" and Nx >= 3600:
                     continue                                           # hundreds of 115 KB messages through a host-staged double: covered by the small cases
-                devs = [torch.from_numpy(a).to(dev) for a in everyone[rank]]
-                ptrs = _lib.ptr_table(devs)
-                for rep in range(2):                                   # twice: mailbox and buffer reuse, message order across calls
-                    rc = call(ptrs)
-                    assert rc == 0, (name, rc, lib.tpg_last_error())
-                torch.cuda.synchronize()
                 want = expect(local_fill)
-                for f, (d, w) in enumerate(zip(devs, want)):
-                    got = d.cpu().numpy()
-                    assert np.array_equal(got, w), f"rank {rank} case {ci} {name} field {f}: {int((got != w).sum())} cells differ"
+                for rep in range(2):                                   # twice on fresh data: mailbox and buffer reuse, message order across calls
+                    # (fresh data, not a second call on the result: the zipper is not idempotent -- the x-Face fold maps i = Nx/2 + 1 of row Ny
+                    # onto itself with the field's sign)
+                    devs = [torch.from_numpy(a).to(dev) for a in everyone[rank]]
+                    rc = call(_lib.ptr_table(devs))
+                    assert rc == 0, (name, rc, lib.tpg_last_error())
+                    torch.cuda.synchronize()
+                    for f, (d, w) in enumerate(zip(devs, want)):
+                        got = d.cpu().numpy()
+                        assert np.array_equal(got, w), f"rank {rank} case {ci} {name} rep {rep} field {f}: {int((got != w).sum())} cells differ"
                 cases += 1
             dist.barrier()
         # a size mismatch between a send and its receive is an error of the double, as it would be on the wire: rank 0 sends 3 fields, rank 1
