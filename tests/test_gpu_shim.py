@@ -100,6 +100,46 @@ def _worker(rank, world, port, out):
                         assert np.array_equal(got, w), f"rank {rank} case {ci} {name} rep {rep} field {f}: {int((got != w).sum())} cells differ"
                 cases += 1
             dist.barrier()
+        # ---- the Python production path: HaloFillPlan on a DistributedTripolarGrid whose architecture carries the communicator = ONE C call per
+        # fill (tpg_fill_halo_regions_distributed[_pipelined]); its plan-build collective (all ranks must agree on the stage layout) runs for
+        # real over the three processes.  Expected: every rank's slab == its rows of the serially filled GLOBAL field (oracle).
+        gsize, ghalo = (48, 36, 2), (4, 4, 1)
+        (Nx, Ny, Nz), (Hx, Hy, Hz) = gsize, ghalo
+        specs4 = SPECS[:4]
+        for stage in (0, 1, 3):
+            rng = np.random.default_rng(4242)                           # the same global data on every rank
+            globs = []
+            for xl_, yl_, sg_ in specs4:
+                g = rng.uniform(-1, 1, (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx))
+                g[:, :Hy] = 12345.0; g[:, Hy + Ny:] = 12345.0
+                globs.append(g)
+            arch = osg.Distributed(osg.GPU(0), osg.Partition(y=world), rccl_comm=comm)      # rank / world from torch.distributed (gloo)
+            assert arch.local_rank == rank
+            grid = osg.TripolarGrid(arch, torch.float64, size=gsize, halo=ghalo)
+            j0, j1 = grid.jrange
+            fs = []
+            for (xl_, yl_, sg_), g in zip(specs4, globs):
+                f = osg.Field((osg.Face if xl_ else osg.Center, osg.Face if yl_ else osg.Center, osg.Center), grid)
+                slab = g[:, j0 - 1:j1 + 2 * Hy].copy()
+                slab[:, :Hy] = 12345.0; slab[:, Hy + (j1 - j0 + 1):] = 12345.0
+                f.data.copy_(torch.from_numpy(slab))
+                fs.append(f)
+            plan = osg.halo_fill_plan(fs, fields_per_stage=stage)
+            assert plan.is_distributed
+            plan()
+            torch.cuda.synchronize()
+            for (xl_, yl_, sg_), g in zip(specs4, globs):
+                oracle.fill_halo_regions(g, xl_, yl_, sg_, gsize, ghalo)
+            for f, g in zip(fs, globs):
+                assert np.array_equal(f.data.cpu().numpy(), g[:, j0 - 1:j1 + 2 * Hy]), f"rank {rank} HaloFillPlan stage {stage} {f.loc}"
+            cases += 1
+        # ranks that disagree on fields_per_stage are caught at plan build, on every rank, before any exchange
+        try:
+            osg.halo_fill_plan(fs, fields_per_stage=2 if rank == 1 else 1)
+            raise AssertionError("ranks disagreed on fields_per_stage and the plan was built")
+        except ValueError as e:
+            assert "disagree" in str(e)
+        dist.barrier()
         # a size mismatch between a send and its receive is an error of the double, as it would be on the wire: rank 0 sends 3 fields, rank 1
         # expects 2 -> rank 1's receive fails (TPG_ERR_RCCL); rank 0's send completes (the message was put); nobody hangs
         if world >= 2 and rank <= 1:
@@ -144,7 +184,7 @@ def test_exchange_entry_points_between_three_processes_over_the_test_double(gpu)
     errors = [g for g in got if g[1] == "error"]
     assert not errors, errors
     oks = {g[0]: g[2] for g in got if g[1] == "ok"}
-    assert oks == {0: 20, 1: 20, 2: 20}, got                          # 7 forms x 3 geometries, minus the large pack-free case
+    assert oks == {0: 23, 1: 23, 2: 23}, got                          # 7 forms x 3 geometries minus the large pack-free case, + 3 HaloFillPlan runs
     mism = {g[0]: g for g in got if g[1] == "mismatch"}
     assert mism[1][2] == -7 and "nccl_shim" in mism[1][3] and mism[0][2] in (0, -7)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
