@@ -31,6 +31,9 @@ fill in both forms, the side-stream overlap with the build, the instrumented pas
 whose south / north peer is the rank itself, for band r of a chain of R (default: band 3 of 8 = an interior band of BASELINE
 config 4 with two seams; band R-1 = the zipper band).  Its seam "transfers" are device-local copies by RCCL's own kernels: a
 rehearsal of the code path, not a scaling measurement, and the line says so.
+Rehearsals for one-GPU boxes (never used by the driver; timings meaningless): TPG_BENCH_REHEARSE=1 (N <= 6 ranks on cuda:0, gloo, the
+fallback transport), =shim (the same ranks through the PRODUCTION branch, librccl's entry points served by the test double tools/nccl_shim
+behind the test library), =plan (start-up only, no device, any N: launcher, rendezvous, band layout, seam pairing).
 
 Order of a run: set-up -> [N > 1: first seam exchange under a deadline, bit-exact seam check, exchange pre-pass] -> the DECLARED
 clock pre-roll (`clock_preroll`: P plain tpg_build_grid calls, ~35 ms, so that a short run starts from the sustained FP64 clock
