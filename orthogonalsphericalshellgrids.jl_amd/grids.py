@@ -262,7 +262,7 @@ class TableWorkspace:
     grid are never overwritten.  `ready` orders a reusing build on another stream after the kernel that wrote the tables."""
 
     def __init__(self, key, tensor):
-        self.key, self.tensor, self.ready = key, tensor, None
+        self.key, self.tensor, self.ready, self.stream = key, tensor, None, None
 
 
 # live workspaces by key (weak: a workspace lives exactly as long as a grid that holds it): consecutive band builds of one geometry --
@@ -302,7 +302,8 @@ def _build(arch, dtype, size, halo, southernmost_latitude, radius, z, north_pole
         reuse = ws is not None and ws.tensor.numel() >= nbytes and ws.ready is not None
         if reuse:
             p.reserved = _lib.TPG_BUILD_TABLES_VALID
-            stream.wait_event(ws.ready)                  # the tables may have been written on another stream
+            if stream.cuda_stream != ws.stream:
+                stream.wait_event(ws.ready)              # the tables were written on another stream (same stream: its order suffices)
         else:
             ws = TableWorkspace(key, torch.empty(nbytes, dtype=torch.uint8, device=device))
         out = _lib.ptr_table([arrays[n] for n in ARRAY_NAMES])
@@ -310,7 +311,7 @@ def _build(arch, dtype, size, halo, southernmost_latitude, radius, z, north_pole
         # the workspace must outlive the asynchronous kernels: tie its release to the stream
         ws.tensor.record_stream(stream)
         if not reuse:
-            ws.ready = torch.cuda.Event()
+            ws.ready, ws.stream = torch.cuda.Event(), stream.cuda_stream
             ws.ready.record(stream)
             with _live_lock:
                 _live_workspaces[key] = ws
