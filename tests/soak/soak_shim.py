@@ -86,6 +86,8 @@ def worker(rank, world, port, trials, seed, out):
             if rank < chain - 1:
                 north = filled(rank + 1)
                 for f in range(nf): want[f][:, Ny + Hy:] = north[f][:, Hy:2 * Hy]
+            if os.environ.get("TPG_SOAK_TEETH") == "1" and t == 3 and rank == 1:
+                devs[0][0, 0, 0] += 1.0                                # self-check of the checker: exactly this must be reported (exit status 1)
             for f in range(nf):
                 if not np.array_equal(devs[f].cpu().numpy(), want[f]):
                     bad += 1; print(f"MISMATCH rank {rank} trial {t} form {form} fps {fps} two {two} chain {chain} geom {g} nf {nf} f64 {f64} field {f}", flush=True); break
