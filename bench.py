@@ -23,9 +23,13 @@ For N > 1 the halo fill (local fill + seam exchange) runs on a side stream besid
 two touch disjoint memory.  Before the warm-up one fill runs under a host-side deadline: a stalled exchange ends the job
 with a one-line JSON diagnostic on stderr and a non-zero exit instead of a silent hang.  The seam exchange has two forms with
 identical results -- monolithic (pack all -> one RCCL group -> unpack all) and pipelined per field on a second stream
-(tpg_halo_exchange_y_pipelined; in stages of 1 and of 2 fields) -- all are timed on every run (`exchange_ms_monolithic`,
-`exchange_ms_pipelined_1`, `exchange_ms_pipelined_2`, beside
-`link_floor_ms`); `--exchange auto` (default) runs the timed steps with whichever was faster (max over ranks).
+(tpg_halo_exchange_y_pipelined; in stages of 1 and of 2 fields).  The run is made with the MONOLITHIC form first (first contact,
+bit-exact seam check, pre-pass, W + K steps, per-phase passes) and rank 0 assembles the line; only then are the pipelined forms
+probed (`--exchange auto`, the default): first contact on fresh fields, seam check, pre-pass, per-phase pass; if one beats the
+monolithic pre-pass (max over ranks) the W + K steps are run again with it and that is `value` (`ms_per_step_by_form` keeps
+both; `exchange_ms_monolithic`, `exchange_ms_pipelined_1`, `exchange_ms_pipelined_2` beside `link_floor_ms`).  A stall or an
+error inside the probe costs the probe, not the run: the line of the monolithic form is printed with `pipelined_probe.status`
+"stalled" / "error" and every rank leaves with status 0.  `--exchange monolithic|pipelined_k` runs that form alone.
 `--loopback` runs that whole N > 1 branch -- communicator bring-up under the watchdog, seam buffers, the one-call distributed
 fill in both forms, the side-stream overlap with the build, the instrumented passes -- on ONE GPU: a communicator of one rank
 whose south / north peer is the rank itself, for band r of a chain of R (default: band 3 of 8 = an interior band of BASELINE
@@ -157,8 +161,12 @@ class Watchdog:
 
     def __init__(self, seconds, info):
         self.seconds, self.info, self.phase, self._timer = seconds, dict(info), "idle", None
+        self.soft = None                    # callable: what to do INSTEAD of failing (the pipelined probe: print the line already in hand)
 
     def _fire(self):
+        if self.soft is not None:
+            self.soft(self)
+            os._exit(0)
         d = dict(self.info, event="bench_deadline_expired", phase=self.phase, deadline_s=self.seconds)
         print(json.dumps(d), file=sys.stderr, flush=True)
         os._exit(3)
@@ -600,37 +608,33 @@ def main():
     # the synthetic fields were written on the NULL stream; the side / comm streams are non-blocking streams and do not wait for it
     torch.cuda.synchronize()
 
-    # ---- N > 1: first contact with the neighbours under a deadline ---------------------------------------------------------
-    if chain:
-        dog.info.update(geometry=list(geom), seam_message_MB=4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8 / 1e6)
-        if os.environ.get("TPG_BENCH_TEST_STALL_RANK") == str(rank):      # tests/test_gpu_bench_contract.py: a rank that never posts its half
-            time.sleep(3 * args.deadline)
-            os._exit(4)
-        for form in FORMS:
-            dog.arm(f"first seam exchange ({form}): enqueue (host inside ncclGroupEnd / batch_isend_irecv)")
-            with torch.cuda.stream(side_stream):
-                distributed_fill(form)
-            dog.set_phase(f"first seam exchange ({form}): device (stream not drained: a peer never posted its half of the group?)")
-            torch.cuda.synchronize()
-            if world > 1:
-                dog.set_phase(f"barrier after the first seam exchange ({form})")
-                dist.barrier()
-            dog.disarm()
-        # ---- the seams just exchanged, checked bit for bit (both forms have run; a fill is idempotent on the rows that travel).  Every
-        # field is synthetic with a seed that names its band, so this rank can REBUILD what its neighbour owns: the neighbour's field,
-        # its local fill (periodic x; the zipper if it is the north band), and from it the interior rows the neighbour sent.  They
-        # must equal the halo rows this rank received -- all columns incl. the x halos, all levels incl. the z halos.  On the driver's
-        # multi-GPU run this is the first bit-exact check of the RCCL path between real ranks; a mismatch ends the job (all ranks
-        # agree first, so nobody is left in a barrier) with a diagnostic and no contract line.
-        dog.arm("seam verification after the first exchanges")
-        seam_check = {"sides": 0, "fields": n, "bit_exact": True, "bad": []}
-        if os.environ.get("TPG_BENCH_TEST_CORRUPT_SEAM") == str(rank):     # tests/test_gpu_bench_contract.py: the check must have teeth
-            fields[1][NZ // 2, (H - 1) if south_peer >= 0 else (ny + H), NX // 2] += 1.0
+    # ---- N > 1 helpers ---------------------------------------------------------------------------------------------------------------
+    # The exchange form of record is `primary`: monolithic, unless --exchange names another.  The other forms are probed in an EPILOGUE, after
+    # everything the contract line needs has been measured with the primary form and the line has been assembled: the pipelined forms have
+    # never met a second RCCL rank, and a stall in one of them must cost their figures, not the run (see `pipelined probe` below).
+    primary = "monolithic" if args.exchange == "auto" else args.exchange
+    if chain and primary not in FORMS:
+        raise SystemExit(f"--exchange {args.exchange}: not available on this transport ({dog.info.get('transport')})")
+
+    def first_contact(form):
+        dog.arm(f"first seam exchange ({form}): enqueue (host inside ncclGroupEnd / batch_isend_irecv)")
+        with torch.cuda.stream(side_stream):
+            distributed_fill(form)
+        dog.set_phase(f"first seam exchange ({form}): device (stream not drained: a peer never posted its half of the group?)")
+        torch.cuda.synchronize()
+        if world > 1:
+            dog.set_phase(f"barrier after the first seam exchange ({form})")
+            dist.barrier()
+        dog.disarm()
+
+    def verify_seams():
+        """(every rank's seams bit-exact?, this rank's record): collective"""
+        chk = {"sides": 0, "fields": n, "bit_exact": True, "bad": []}
         scratch = torch.empty(shape, dtype=torch.float64, device=dev)
         for side, nb in (("south", band - 1), ("north", band + 1)):
             if not (0 <= nb < bands):
                 continue
-            seam_check["sides"] += 1
+            chk["sides"] += 1
             owner = band if loopback else nb                          # loop-back: the "neighbour" on either side is this band itself
             for fid, (name, fxl, fyl, fsg) in enumerate(SPECS):
                 testlib.check(tlib.tpg_fill_synthetic(scratch.data_ptr(), 0x5EED + fid + 16 * owner, 12345.0, NX, ny, NZ, H, H, H, _lib.TPG_F64, None))
@@ -646,17 +650,79 @@ def main():
                 else:                                                 # my halo rows j = ny+1..ny+Hy  <-  its interior rows j = 1..Hy
                     got, want = fields[fid][:, ny + H:], (scratch[:, ny:ny + H] if one_seam_loop else scratch[:, H:2 * H])
                 if not torch.equal(got, want):
-                    seam_check["bit_exact"] = False
+                    chk["bit_exact"] = False
                     ne = (got != want).nonzero()
-                    seam_check["bad"].append({"side": side, "field": name, "cells": int(ne.shape[0]),
-                                              "first_level_row_col": ne[0].tolist(), "last_level_row_col": ne[-1].tolist()})
+                    chk["bad"].append({"side": side, "field": name, "cells": int(ne.shape[0]),
+                                       "first_level_row_col": ne[0].tolist(), "last_level_row_col": ne[-1].tolist()})
         del scratch
-        agree = torch.tensor([1 if seam_check["bit_exact"] else 0], dtype=torch.int32, device=None if rehearse else dev)
+        agree = torch.tensor([1 if chk["bit_exact"] else 0], dtype=torch.int32, device=None if rehearse else dev)
         if world > 1:
             dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        return int(agree.item()) == 1, chk
+
+    def prepass_time(form):
+        """fill + exchange alone on the side stream, no build beside it: 6 back-to-back fills after 2 untimed ones, max over ranks"""
+        sync()
+        with torch.cuda.stream(side_stream):
+            for _ in range(2):
+                distributed_fill(form)
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(6):
+                distributed_fill(form)
+            e1.record()
+        torch.cuda.synchronize()
+        return reduce_max(e0.elapsed_time(e1) / 6)
+
+    def instrument_form(form, with_kernel_events):
+        """K x [local fill, exchange] alone on the side stream with an event pair around each part: (local ms, exchange ms, fill kernel ms)"""
+        marks = [[ev() for _ in range(3)] for _ in range(args.steps)]
+        kev2 = [(hip_event(), hip_event()) for _ in range(args.steps)] if with_kernel_events else None
+        sync()
+        with torch.cuda.stream(side_stream):
+            for k in range(args.steps):
+                m = marks[k]
+                m[0].record(); local_fill(kev2[k] if kev2 else None); m[1].record(); exchange_only(form); m[2].record()
+        sync()
+        avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)
+        tk = 0.0
+        if kev2:
+            tk = sum(elapsed_ms(e0, e1) for e0, e1 in kev2) / len(kev2)
+            for e0, e1 in kev2:
+                lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
+        return avg(0, 1), avg(1, 2), tk
+
+    def timed_chain_steps():
+        """exactly W warm-up + K timed steps of the N > 1 step with the form in used_form[0]; seconds for the K steps, max over ranks"""
+        sync()
+        for _ in range(args.warmup):
+            step()
+        sync()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        return reduce_max(time.perf_counter() - t0_)
+
+    # ---- N > 1: first contact with the neighbours under a deadline ---------------------------------------------------------
+    if chain:
+        dog.info.update(geometry=list(geom), seam_message_MB=4 * (NX + 2 * H) * H * (NZ + 2 * H) * 8 / 1e6)
+        if os.environ.get("TPG_BENCH_TEST_STALL_RANK") == str(rank):      # tests/test_gpu_bench_contract.py: a rank that never posts its half
+            time.sleep(3 * args.deadline)
+            os._exit(4)
+        first_contact(primary)
+        # ---- the seams just exchanged, checked bit for bit.  Every field is synthetic with a seed that names its band, so this rank can
+        # REBUILD what its neighbour owns: the neighbour's field, its local fill (periodic x; the zipper if it is the north band), and from
+        # it the interior rows the neighbour sent.  They must equal the halo rows this rank received -- all columns incl. the x halos, all
+        # levels incl. the z halos.  On the driver's multi-GPU run this is the first bit-exact check of the RCCL path between real ranks; a
+        # mismatch ends the job (all ranks agree first, so nobody is left in a barrier) with a diagnostic and no contract line.
+        dog.arm("seam verification after the first exchange")
+        if os.environ.get("TPG_BENCH_TEST_CORRUPT_SEAM") == str(rank):     # tests/test_gpu_bench_contract.py: the check must have teeth
+            fields[1][NZ // 2, (H - 1) if south_peer >= 0 else (ny + H), NX // 2] += 1.0
+        all_ok, seam_check = verify_seams()
         if not seam_check["bit_exact"]:
             print(json.dumps(dict(dog.info, event="seam_mismatch", **seam_check)), file=sys.stderr, flush=True)
-        if int(agree.item()) == 0:
+        if not all_ok:
             dog.disarm()
             os._exit(6)                                               # every rank leaves: the exchange delivered wrong halos somewhere
         dog.disarm()
@@ -665,28 +731,11 @@ def main():
         dog.seconds = max(10 * args.deadline, 600.0)
         dog.arm("exchange pre-pass / warm-up / timed / instrumented steps (a seam exchange after the first one never completed)")
 
-    # ---- N > 1: which exchange form do the timed steps use?  Both are measured (fill + exchange alone on the side stream, no build
-    # beside it, 6 back-to-back fills after 2 untimed ones, one event pair around the lot, max over ranks); auto = the faster one ----
+    # ---- N > 1: the exchange form of record (fill + exchange alone, pre-pass figure; the other forms follow in the epilogue) -----------
     prepass = {}
     if chain:
-        for form in FORMS:
-            sync()
-            with torch.cuda.stream(side_stream):
-                for _ in range(2):
-                    distributed_fill(form)
-                e0, e1 = ev(), ev()
-                e0.record()
-                for _ in range(6):
-                    distributed_fill(form)
-                e1.record()
-            torch.cuda.synchronize()
-            prepass[form] = reduce_max(e0.elapsed_time(e1) / 6)
-        if args.exchange != "auto":
-            if args.exchange not in FORMS:
-                raise SystemExit(f"--exchange {args.exchange}: not available on this transport ({dog.info.get('transport')})")
-            used_form[0] = args.exchange
-        else:
-            used_form[0] = min(FORMS, key=lambda f: prepass[f])     # the same on every rank: prepass holds max-over-ranks values
+        prepass[primary] = prepass_time(primary)
+        used_form[0] = primary
 
     # ---- declared clock pre-roll (not steps) ---------------------------------------------------------------------------------
     # The FP64-heavy cell kernel starts a power-management transient whenever it follows lighter work -- 535 us on its first launch, up
@@ -766,39 +815,31 @@ def main():
         b1.record()
         sync()
         t_build_steady = b0.elapsed_time(b1) / 100
-        t_fill_kernel, local_ms = 0.0, {}
-        for form in FORMS:
-            marks = [[ev() for _ in range(3)] for _ in range(args.steps)]
-            kev2 = [(hip_event(), hip_event()) for _ in range(args.steps)] if (north_is_zipper and form == "monolithic") else None
-            sync()
-            with torch.cuda.stream(side_stream):
-                for k in range(args.steps):
-                    m = marks[k]
-                    m[0].record(); local_fill(kev2[k] if kev2 else None); m[1].record(); exchange_only(form); m[2].record()
-            sync()
-            avg = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / len(marks)
-            local_ms[form], ex_ms[form] = avg(0, 1), avg(1, 2)
-            if kev2:
-                t_fill_kernel = sum(elapsed_ms(e0, e1) for e0, e1 in kev2) / len(kev2)
-                for e0, e1 in kev2:
-                    lib.tpg_event_destroy(e0); lib.tpg_event_destroy(e1)
-        uf = used_form[0]
-        t_fill_bracket, t_exchange, t_fillx = local_ms[uf], ex_ms[uf], local_ms[uf] + ex_ms[uf]
-        # every band's own phase times travel to rank 0 for the line: at N = 8 the interior ranks carry two seams, the end ranks one,
-        # and only the north rank folds
-        mine = {"rank": rank, "band": band, "rows": [jstart, jend], "seams_bit_exact": seam_check["bit_exact"], "build_ms": t_build,
-                "build_steady_ms": t_build_steady, "local_fill_ms": t_fill_bracket,
-                "exchange_ms": t_exchange, "exchange_ms_by_form": dict(ex_ms), "fill_plus_exchange_ms": t_fillx,
-                "seams": int(south_peer >= 0) + int(north_peer >= 0), "zipper": north_is_zipper}
-        per_rank = [None] * world
-        if world > 1:
-            dist.all_gather_object(per_rank, mine)
-        else:
-            per_rank = [mine]
-        t_build, t_exchange, t_fillx = reduce_max(t_build), reduce_max(t_exchange), reduce_max(t_fillx)
-        t_build_steady = reduce_max(t_build_steady)
-        ex_ms = {f: reduce_max(v) for f, v in ex_ms.items()}
+        local_ms = {}
+        local_ms[primary], ex_ms[primary], t_fill_kernel = instrument_form(primary, north_is_zipper)
+        own_build, own_build_steady = t_build, t_build_steady
+        t_build, t_build_steady = reduce_max(t_build), reduce_max(t_build_steady)
         t_fill_kernel = reduce_max(t_fill_kernel)                                    # only the zipper band has one
+        cs = {}                                                                       # the chain's summary for the line (refreshed after the epilogue)
+
+        def refresh_chain_summary():
+            """collective: every band's own phase times travel to rank 0 (at N = 8 the interior ranks carry two seams, the end ranks one, and
+            only the north rank folds); the figures of the form in used_form[0] become the line's exchange_ms / fill_plus_exchange_ms"""
+            uf = used_form[0]
+            mine = {"rank": rank, "band": band, "rows": [jstart, jend], "seams_bit_exact": seam_check["bit_exact"], "build_ms": own_build,
+                    "build_steady_ms": own_build_steady, "local_fill_ms": local_ms[uf],
+                    "exchange_ms": ex_ms[uf], "exchange_ms_by_form": dict(ex_ms), "fill_plus_exchange_ms": local_ms[uf] + ex_ms[uf],
+                    "seams": int(south_peer >= 0) + int(north_peer >= 0), "zipper": north_is_zipper}
+            pr = [None] * world
+            if world > 1:
+                dist.all_gather_object(pr, mine)
+            else:
+                pr = [mine]
+            cs.update(per_rank=pr, t_fill_bracket=local_ms[uf], t_exchange=reduce_max(ex_ms[uf]), t_fillx=reduce_max(local_ms[uf] + ex_ms[uf]),
+                      ex_ms_max={f: reduce_max(ex_ms[f]) for f in sorted(ex_ms)})
+
+        refresh_chain_summary()
+        t_fill_bracket, t_exchange, t_fillx = None, None, None                       # chain: read from `cs`
 
     # ---- N = 1: fold-only pass, K old-style steps (build -> tpg_zipper_fill [k_zipper_cols] -> tpg_periodic_x_fill) -------
     fold = None
@@ -843,8 +884,11 @@ def main():
         torch.cuda.empty_cache()                                               # config 5 wants 162 GB + headroom
         fill_step = fill_step_config5(torch, osg, _lib, tlib, dev)
 
-    if rank == 0:
+    def make_line(elapsed):
         ms_per_step = elapsed / args.steps * 1e3
+        t_fill_bracket_, t_exchange, t_fillx = (cs["t_fill_bracket"], cs["t_exchange"], cs["t_fillx"]) if chain else (t_fill_bracket, None, None)
+        ex_ms_max = cs["ex_ms_max"] if chain else {}
+        per_rank = cs["per_rank"] if chain else None
         # cells of one step: the whole globe (all bands) -- in loop-back only this band's share of it exists
         cells = gsize[0] * gsize[1] if not loopback else NX * ny
         zbytes = sum(zipper_algorithmic_bytes(NX, NZ, H).values())
@@ -872,7 +916,7 @@ def main():
             "clock_preroll": preroll,
             "ms_per_step_cold_onset": cold_onset["ms_per_step"] if cold_onset else None, "cold_onset": cold_onset,
             "precompute_cells_per_s": cells / (t_build * 1e-3),            # N > 1: all bands / the slowest rank's build
-            "precompute_ms": t_build, "fill_ms": t_fill_kernel, "fill_bracket_ms": t_fill_bracket,
+            "precompute_ms": t_build, "fill_ms": t_fill_kernel, "fill_bracket_ms": t_fill_bracket_,
             "fill_GBps": fill_bytes / (t_fill_kernel * 1e-3) / 1e9 if t_fill_kernel else None,
         }
         if chain:
@@ -887,10 +931,10 @@ def main():
                 "overlap": "halo fill (local fill + seam exchange) on a side stream, concurrent with the grid build" if overlap else None,
                 "exchange_ms": t_exchange,                          # the form the timed steps used; pack + send/recv + unpack, slowest rank
                 "exchange_form": used_form[0], "exchange_form_choice": args.exchange,
-                "exchange_ms_monolithic": ex_ms.get("monolithic"),
-                "exchange_ms_pipelined": min((v for f, v in ex_ms.items() if f.startswith("pipelined")), default=None),   # the better of the two stage sizes
-                "exchange_ms_pipelined_1": ex_ms.get("pipelined_1"), "exchange_ms_pipelined_2": ex_ms.get("pipelined_2"),     # stages of 1 / 2 fields
-                "exchange_prepass_fill_ms": prepass,                # whole fill (local + exchange), back to back, per form: what `auto` chose on
+                "exchange_ms_monolithic": ex_ms_max.get("monolithic"),
+                "exchange_ms_pipelined": min((v for f, v in ex_ms_max.items() if f.startswith("pipelined")), default=None),   # the better of the two stage sizes
+                "exchange_ms_pipelined_1": ex_ms_max.get("pipelined_1"), "exchange_ms_pipelined_2": ex_ms_max.get("pipelined_2"),     # stages of 1 / 2 fields
+                "exchange_prepass_fill_ms": dict(prepass),                # whole fill (local + exchange), back to back, per form: what `auto` chose on
                 "link_floor_ms": seam_bytes / 153.6e9 * 1e3,        # one seam direction over one xGMI link at its ~153.6 GB/s spec figure
                 # the band build past the cell kernel's power-management transient (300 untimed + 100 timed builds, slowest rank); `precompute_ms`
                 # is K builds right after the timed steps, which with few steps still sit inside it
@@ -957,6 +1001,93 @@ def main():
             "algorithmic_bytes_per_launch": 160 * band_cells, "traffic": traffic.get("k_cells_tile"),
             "note": "FP64-issue bound (VALU busy 91 %%): %.1f of the %.1f TFLOP/s vector FP64 peak at 2.29 kflop/cell (PMC count); the 160 B/cell store "
                     "stream is %.0f %%%% of HBM peak" % (tflops, FP64_VALU_PEAK_TFLOPS, 100 * 160.0 * band_cells / (t_build * 1e-3) / 1e9 / HBM_PEAK_GBPS)}
+        return line
+
+    # ---- N > 1: the pipelined probe (epilogue) -----------------------------------------------------------------------------------------------
+    # Everything the line needs has been measured with the primary form, and rank 0 holds the line.  Only now are the other exchange forms
+    # tried: first contact on freshly synthesised fields (so that a form that delivers nothing cannot pass on the primary form's halos), the
+    # bit-exact seam check, the pre-pass figure, the per-phase pass.  If a probed form's pre-pass (max over ranks) beats the primary's, the W
+    # + K steps are run again with it and THAT is `value` (`ms_per_step_by_form` keeps both).  A stall anywhere in here fires the watchdog in
+    # its SOFT mode: one JSON diagnostic on stderr, rank 0 prints the line it already holds with `pipelined_probe.status = "stalled"`, every
+    # rank leaves with status 0 -- the pipelined forms have never met a second RCCL rank, and their first contact must not cost the run.
+    final_line = make_line(elapsed) if rank == 0 else None
+    steps_by_form = {used_form[0]: elapsed / args.steps * 1e3} if chain else None
+    if chain and rank == 0:
+        final_line["ms_per_step_by_form"] = dict(steps_by_form)
+        final_line["pipelined_probe"] = {"status": "not run", "why": "no C-ABI communicator" if comm is None else ("--exchange " + args.exchange)}
+    if chain and comm is not None and args.exchange == "auto" and len(FORMS) > 1:
+        probe = {"status": "ok", "forms": {}}
+
+        def soft_expiry(d):
+            print(json.dumps(dict(d.info, event="pipelined_probe_stalled", phase=d.phase, deadline_s=d.seconds)), file=sys.stderr, flush=True)
+            if rank == 0:
+                final_line["pipelined_probe"] = {"status": "stalled", "phase": d.phase, "forms": probe["forms"],
+                                                 "note": "the line is the primary (monolithic) form's; a pipelined form did not complete in time"}
+                contract_out.write(json.dumps(final_line) + "\n")
+                contract_out.flush()
+
+        try:
+            dog.disarm()
+            dog.soft, dog.seconds = soft_expiry, args.deadline
+            for form in [f for f in FORMS if f != primary]:
+                dog.arm(f"pipelined probe ({form}): first exchange on fresh fields")
+                if os.environ.get("TPG_BENCH_TEST_STALL_PIPELINED") == str(rank):     # tests: a rank that never enters the probe
+                    time.sleep(3 * args.deadline)
+                for fid, f in enumerate(fields):
+                    testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0x5EED + fid + 16 * band, 12345.0, NX, ny, NZ, H, H, H, _lib.TPG_F64, None))
+                torch.cuda.synchronize()
+                with torch.cuda.stream(side_stream):
+                    distributed_fill(form)
+                dog.set_phase(f"pipelined probe ({form}): device (stream not drained)")
+                torch.cuda.synchronize()
+                if world > 1:
+                    dog.set_phase(f"pipelined probe ({form}): barrier after the first exchange")
+                    dist.barrier()
+                dog.set_phase(f"pipelined probe ({form}): seam verification")
+                ok, chk = verify_seams()
+                if not ok:
+                    probe["forms"][form] = "seam_mismatch"
+                    probe["status"] = "seam_mismatch"
+                    if not chk["bit_exact"]:
+                        print(json.dumps(dict(dog.info, event="seam_mismatch", form=form, **chk)), file=sys.stderr, flush=True)
+                    for fid, f in enumerate(fields):                               # leave correct halos behind: the primary form again
+                        testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0x5EED + fid + 16 * band, 12345.0, NX, ny, NZ, H, H, H, _lib.TPG_F64, None))
+                    torch.cuda.synchronize()
+                    with torch.cuda.stream(side_stream):
+                        distributed_fill(primary)
+                    torch.cuda.synchronize()
+                    continue
+                dog.arm(f"pipelined probe ({form}): pre-pass and per-phase pass")
+                prepass[form] = prepass_time(form)
+                local_ms[form], ex_ms[form], _ = instrument_form(form, False)
+                probe["forms"][form] = "ok"
+            best = min(prepass, key=lambda f: prepass[f])                           # the same on every rank: max-over-ranks values
+            if best != primary:
+                dog.arm(f"pipelined probe: W + K steps with {best}")
+                used_form[0] = best
+                steps_by_form[best] = timed_chain_steps() / args.steps * 1e3
+            dog.arm("pipelined probe: gathering the ranks' figures")
+            refresh_chain_summary()
+            dog.disarm()
+            dog.soft = None
+            if rank == 0:
+                final_line = make_line(steps_by_form[used_form[0]] * 1e-3 * args.steps)
+                final_line["ms_per_step_by_form"] = dict(steps_by_form)
+                final_line["pipelined_probe"] = probe
+        except Exception as e:                                          # noqa: BLE001 -- an ERROR in a probed form (not a stall) must not cost the run either
+            dog.disarm()
+            print(json.dumps(dict(dog.info, event="pipelined_probe_failed", error=f"{type(e).__name__}: {e}"[:500], forms=probe["forms"])),
+                  file=sys.stderr, flush=True)
+            used_form[0] = primary
+            if rank == 0:
+                primary_line = make_line(elapsed)                       # the primary form's figures (the summary may be half refreshed: rebuild from `cs`)
+                primary_line["ms_per_step_by_form"] = {primary: elapsed / args.steps * 1e3}
+                primary_line["pipelined_probe"] = {"status": "error", "error": f"{type(e).__name__}: {e}"[:500], "forms": probe["forms"]}
+                contract_out.write(json.dumps(primary_line) + "\n")
+                contract_out.flush()
+            os._exit(0)                                                 # the other ranks leave through their soft watchdogs
+    if rank == 0:
+        line = final_line
         if not chain and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         contract_out.write(json.dumps(line) + "\n")          # ASCII-escaped: safe under any stdout encoding

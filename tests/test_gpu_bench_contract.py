@@ -114,6 +114,7 @@ def test_bench_two_ranks_rehearsal(gpu):
     assert d["config"]["rows_per_rank"] == 900 and d["config"]["parallelism"] == "latitude-bands x2" and "config 4" in d["config"]["workload"]
     assert isinstance(d["exchange_ms"], float) and d["exchange_ms"] > 0 and "gloo" in d["exchange_transport"]
     assert d["exchange_form"] == "monolithic" and d["exchange_ms_monolithic"] == d["exchange_ms"] and d["exchange_ms_pipelined"] is None
+    assert d["pipelined_probe"]["status"] == "not run" and d["ms_per_step_by_form"] == {"monolithic": d["ms_per_step"]}    # fallback transport: one form
     assert abs(d["link_floor_ms"] - 4 * 3608 * 4 * 83 * 8 / 153.6e9 * 1e3) < 1e-9
     assert d["seam_GBps_per_direction"] > 0 and d["overlap"] is not None and 0.0 <= d["overlap_hidden_frac"] <= 1.0
     assert d["exchange_over_build"] > 0 and d["fill_plus_exchange_ms"] >= d["exchange_ms"]
@@ -171,6 +172,31 @@ def test_bench_production_branch_between_real_processes_over_the_test_double(gpu
     assert [r["seams"] for r in pr] == [1, 2, 2, 1] and [r["zipper"] for r in pr] == [False, False, False, True]
     assert all(r["seams_bit_exact"] for r in pr) and all(set(r["exchange_ms_by_form"]) == forms for r in pr)
     assert d["roofline"]["launch_ms"] > 0                                                              # the zipper band's merged fold ran (rank 3)
+    # the run was made with the monolithic form first; the pipelined forms were probed afterwards (fresh fields, seam check, pre-pass) and passed
+    assert d["pipelined_probe"] == {"status": "ok", "forms": {"pipelined_1": "ok", "pipelined_2": "ok"}}
+    assert "monolithic" in d["ms_per_step_by_form"] and d["ms_per_step"] == d["ms_per_step_by_form"][d["exchange_form"]]
+
+
+def test_bench_a_stalled_pipelined_probe_costs_the_probe_not_the_run(gpu):
+    """The pipelined exchange forms have never met a second RCCL rank.  They are probed only AFTER the run has been made with the monolithic
+    form and rank 0 holds the line; here rank 1 of a two-rank run through the production branch (test double of librccl) never enters the
+    probe (TPG_BENCH_TEST_STALL_PIPELINED): the soft watchdog must print ONE diagnostic per rank on stderr, rank 0 must still print the
+    contract line -- the monolithic form's, `pipelined_probe.status == "stalled"`, no pipelined figures -- and the job must exit 0."""
+    env = dict(os.environ, TPG_BENCH_REHEARSE="shim", MASTER_ADDR="127.0.0.1", TPG_BENCH_TEST_STALL_PIPELINED="1", TPG_SHIM_DEADLINE_S="120")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TPG_RCCL_LIBRARY"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--preroll", "8", "--deadline", "10"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0 and time.time() - t0 < 200, (p.returncode, p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["pipelined_probe"]["status"] == "stalled" and "pipelined probe (pipelined_1)" in d["pipelined_probe"]["phase"]
+    assert d["exchange_form"] == "monolithic" and d["exchange_ms_monolithic"] > 0 and d["exchange_ms_pipelined_1"] is None
+    assert d["ms_per_step_by_form"] == {"monolithic": d["ms_per_step"]} and all(r["seams_bit_exact"] for r in d["per_rank"])
+    diag = [json.loads(l[l.index("{"):]) for l in p.stderr.splitlines() if "pipelined_probe_stalled" in l]
+    assert {x["rank"] for x in diag} == {0, 1}
 
 
 def test_bench_stalled_teardown_is_reported(gpu):
