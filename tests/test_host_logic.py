@@ -140,6 +140,15 @@ def test_bench_watchdog_fires_with_one_json_line():
     d = json.loads(lines[0])
     assert d["event"] == "bench_deadline_expired" and d["rank"] == 2 and d["peers"] == {"south": 1, "north": 3}
     assert d["phase"] == "first seam exchange: device" and d["deadline_s"] == 0.3
+    # SOFT mode (the pipelined probe of an N > 1 run): on expiry the callback runs -- it prints what the run already holds -- and the
+    # process leaves with status 0 instead of 3, also from under a blocked main thread
+    code3 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+             "d = bench.Watchdog(0.3, {'rank': 0})\n"
+             "d.soft = lambda dog: print('LINE-IN-HAND after', dog.phase, flush=True)\n"
+             "d.arm('pipelined probe (pipelined_1): first exchange'); time.sleep(20); print('not reached')\n" % root)
+    p3 = subprocess.run([sys.executable, "-c", code3], capture_output=True, text=True, timeout=60)
+    assert p3.returncode == 0 and "not reached" not in p3.stdout and "LINE-IN-HAND after pipelined probe (pipelined_1): first exchange" in p3.stdout
+    assert "bench_deadline_expired" not in p3.stderr
     # a disarmed watchdog does nothing
     code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
              "d = bench.Watchdog(0.2, {}); d.arm('x'); d.disarm(); time.sleep(0.6); print('alive')\n" % root)
