@@ -29,7 +29,10 @@ def worker(rank, world, port, trials, seed, out):
         cs = torch.cuda.Stream(dev)
         rng = np.random.default_rng(seed)                               # the SAME stream of cases on every rank
         bad = 0
+        parent = os.getppid()
         for t in range(trials):
+            if os.getppid() != parent:                                  # the launcher is gone (killed by a time limit): do not linger on the GPU
+                os._exit(2)
             Nx = 2 * int(rng.integers(2, 40)); Nz = int(rng.integers(1, 4))
             Hx = int(rng.integers(0, min(Nx, 4) + 1)); Hy = int(rng.integers(1, 5)); Hz = int(rng.integers(0, 3))
             Ny = int(rng.integers(2 * Hy + 1, 2 * Hy + 12))
