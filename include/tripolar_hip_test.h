@@ -11,7 +11,8 @@
  *    TPG_CELLS_VARIANT        cell kernel of tpg_build_grid: 3 LDS tile (default), 0 thread per cell (cross-check)
  *    TPG_BUILD_NT             1 streaming stores in tpg_build_grid (default), 0 plain stores
  *    TPG_ZIPPER_VARIANT       3 column work items (default), 0 row work items (the fallback kernels, everywhere)
- *    TPG_FILL_FUSED           0 never / 1 always (where valid) use the fused small-field fill
+ *    TPG_FILL_FUSED           0 never / 1 always (where valid) use the fused small-field fill; 2 = always, in its one-thread-per-cell form
+ *                             (k_fill_fused: the cross-check of the chunk-item form, which every geometry has since round 6)
  *    TPG_FILL_MERGED          0 never / 1 always (where valid) use the merged large-field fill
  *    TPG_EXCHANGE_IN_CAPTURE  1 lets tpg_halo_exchange_y through on a capturing stream (tools/rccl_capture_probe.py only)
  *    TPG_EXCHANGE_FAIL_STAGE  k >= 0: tpg_halo_exchange_y_pipelined* returns an injected TPG_ERR_RCCL right after the RCCL group of

@@ -49,7 +49,7 @@ struct Config {
     int cells_variant;        // TPG_CELLS_VARIANT  3 LDS-tile kernel (default), 0 thread-per-cell cross-check
     bool build_nt;            // TPG_BUILD_NT       1 streaming stores in tpg_build_grid (default), 0 plain
     int zipper_variant;       // TPG_ZIPPER_VARIANT 3 column items (default), 0 row items (the fallback kernels)
-    int fill_fused;           // TPG_FILL_FUSED     -1 automatic (default), 0 never, 1 wherever valid
+    int fill_fused;           // TPG_FILL_FUSED     -1 automatic (default), 0 never, 1 wherever valid, 2 wherever valid in the one-thread-per-cell form
     int fill_merged;          // TPG_FILL_MERGED    -1 automatic (default), 0 never, 1 wherever valid
     bool exchange_in_capture; // TPG_EXCHANGE_IN_CAPTURE  0 (default): the RCCL seam exchange refuses a capturing stream; 1: lets it through
                               //                          (tools/rccl_capture_probe.py, the diagnostic of the round-2 capture stall)

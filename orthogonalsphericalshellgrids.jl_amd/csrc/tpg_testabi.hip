@@ -53,8 +53,8 @@ int tpg_zipper_copy_probe(void* const fields[], int nfields, const int8_t yloc[]
     Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
     tpg::ev_start = static_cast<hipEvent_t>(start_event);
     tpg::ev_stop = static_cast<hipEvent_t>(stop_event);
-    rc = (ft == TPG_F64) ? zipper_batch<double, 2, true>(fields, nfields, xl, yloc, sg, g, 1, Nz, tpg::as_stream(stream))
-                         : zipper_batch<float, 4, true>(fields, nfields, xl, yloc, sg, g, 1, Nz, tpg::as_stream(stream));
+    rc = (ft == TPG_F64) ? zipper_batch<double, true>(fields, nfields, xl, yloc, sg, g, 1, Nz, tpg::as_stream(stream))
+                         : zipper_batch<float, true>(fields, nfields, xl, yloc, sg, g, 1, Nz, tpg::as_stream(stream));
     tpg::ev_start = tpg::ev_stop = nullptr;
     return rc;
 }

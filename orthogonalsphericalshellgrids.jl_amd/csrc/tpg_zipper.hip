@@ -15,8 +15,8 @@
 //    / 4-B (f32) off 16-B alignment, read with dword-aligned wide loads;
 //  * a 1-D grid of 256-thread blocks, grid-stride free (one item per thread), 64-bit element
 //    offsets, 32-bit item indices.
-// Geometries whose rows are not 16-B chunkable (odd Hx for f64, Hx or Nx not multiple of 4 for
-// f32, misaligned base pointers) run the scalar kernel (one element per item).
+// Geometries whose rows do not split into 16-B aligned chunks (odd Hx -- the reference's model halo (5, 5, 5) --, Float32 with Nx = 2 mod 4,
+// 16-B-misaligned base pointers) run the same kernels in their GEN form: the same chunks, stored element-aligned (tpg_zipper_kernels.hpp).
 #include "tpg_zipper_kernels.hpp"
 
 namespace tpg {
@@ -51,8 +51,8 @@ int tpg_zipper_fill(void* const fields[], int nfields, const int8_t xloc[], cons
     hipStream_t s = tpg::as_stream(stream);
     for (int f0 = 0; f0 < nfields; f0 += TPG_MAX_FIELDS) {
         int n = nfields - f0 < TPG_MAX_FIELDS ? nfields - f0 : TPG_MAX_FIELDS;
-        rc = (ft == TPG_F64) ? zipper_batch<double, 2>(fields + f0, n, xloc + f0, yloc + f0, sign + f0, g, kstart, kcount, s)
-                             : zipper_batch<float, 4>(fields + f0, n, xloc + f0, yloc + f0, sign + f0, g, kstart, kcount, s);
+        rc = (ft == TPG_F64) ? zipper_batch<double>(fields + f0, n, xloc + f0, yloc + f0, sign + f0, g, kstart, kcount, s)
+                             : zipper_batch<float>(fields + f0, n, xloc + f0, yloc + f0, sign + f0, g, kstart, kcount, s);
         if (rc) return rc;
     }
     return TPG_OK;
@@ -137,7 +137,7 @@ int tpg_fill_halo_regions(void* const fields[], int nfields, const int8_t xloc[]
     if (north_is_zipper && mode != 0 && Hx > 0 && Hy > 0 && Nx >= 2 * Hx + 2 && Ny >= 2 * Hy + 2) {
         const long long per_level = (long long)(Hy + 1) * (Nx + 2 * Hx) + 2ll * Hx * (Ny + Hy - 1);
         const long long items = per_level * (Nz + 2 * Hz);
-        if (items < (1ll << 31) && (mode == 1 || items * nfields <= (1ll << 20))) {
+        if (items < (1ll << 31) && (mode >= 1 || items * nfields <= (1ll << 20))) {
             if ((rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft))) return rc;
             if ((rc = check_fields(fields, nfields))) return rc;
             if (!xloc || !yloc || !sign) { tpg::set_error("null location/sign table"); return TPG_ERR_INVALID_ARGUMENT; }
@@ -155,17 +155,17 @@ int tpg_fill_halo_regions(void* const fields[], int nfields, const int8_t xloc[]
                 t.nfields = n;
                 for (int f = 0; f < n; ++f) { t.ptr[f] = fields[f0 + f]; t.xloc[f] = xloc[f0 + f]; t.yloc[f] = yloc[f0 + f]; t.sign[f] = sign[f0 + f]; t.item0[f] = 0; }
                 t.item0[n] = 0;
-                // 16-byte form wherever rows are chunkable and the fields 16-B aligned; one thread per cell otherwise
-                const int W = ft == TPG_F64 ? 2 : 4;
-                bool vec = (Hx % W == 0) && (Nx % W == 0);
-                for (int f = 0; f < n && vec; ++f) vec = ((uintptr_t)t.ptr[f] % 16) == 0;
-                if (vec) {
-                    FusedVecArgs v{ Nx, Ny, Hx, Hy, Hz, Nz, g.sx, (long long)g.sx * g.sy, g.sx / W, 2 * Hx / W, 0, 0 };
+                // chunk items (plain or GEN: chunk_plan); TPG_FILL_FUSED=2 (test library) forces the one-thread-per-cell form k_fill_fused
+                if (mode != 2) {
+                    const ChunkPlan cp = ft == TPG_F64 ? chunk_plan<double>(g, t.ptr, n) : chunk_plan<float>(g, t.ptr, n);
+                    const int W = cp.W, r = cp.gen ? Hx % W : 0;
+                    FusedVecArgs v{ Nx, Ny, Hx, Hy, Hz, Nz, g.sx, (long long)g.sx * g.sy, cp.gen ? 2 * (Hx / W) + Nx / W : g.sx / W,
+                                    cp.gen ? Hx : 2 * Hx / W, 0, 0, r, (Hy + 1) * 2 * r };
                     v.itemsA = (Hy + 1) * v.cpr;
-                    v.per_level = v.itemsA + (Ny + Hy - 1) * v.hc;
+                    v.per_level = v.itemsA + v.itemsS + (Ny + Hy - 1) * v.hc;
                     dim3 gridv((unsigned)(((long long)v.per_level * (Nz + 2 * Hz) + 255) / 256), (unsigned)n);
-                    if (ft == TPG_F64) TPG_LAUNCH((k_fill_fused_vec<double, 2>), gridv, dim3(256), s, t, v);
-                    else               TPG_LAUNCH((k_fill_fused_vec<float, 4>), gridv, dim3(256), s, t, v);
+                    if (ft == TPG_F64) fused_vec_dispatch<double>(gridv, s, t, v, cp);
+                    else               fused_vec_dispatch<float>(gridv, s, t, v, cp);
                 } else {
                     dim3 grid((unsigned)((items + 255) / 256), (unsigned)n);
                     if (ft == TPG_F64) TPG_LAUNCH(k_fill_fused<double>, grid, dim3(256), s, t, a);
@@ -176,17 +176,19 @@ int tpg_fill_halo_regions(void* const fields[], int nfields, const int8_t xloc[]
             return TPG_OK;
         }
     }
-    // large fields: zipper (with its corner cells) + periodic x merged into one launch; TPG_FILL_MERGED=0 never
-    const int W = ft == TPG_F64 ? 2 : 4;
+    // large fields: zipper (with its corner cells) + periodic x merged into one launch (plain or GEN: chunk_plan); TPG_FILL_MERGED=0 never
     if (north_is_zipper && tpg::config().fill_merged != 0 && Hx > 0 && Hy >= 1 && Hy <= 8 && Nx >= 2 * Hx + 2 && Ny >= 2 * Hy + 2
-        && Hx % W == 0 && Nx % W == 0 && (long long)Nz * ((Nx + 2 * Hx) / W) < (1ll << 31) - 256) {
-        bool aligned = fields && xloc && yloc && sign;
-        for (int f = 0; f < nfields && aligned; ++f)
-            aligned = fields[f] && ((uintptr_t)fields[f] % 16) == 0 && (xloc[f] == TPG_CENTER || xloc[f] == TPG_FACE)
-                      && (yloc[f] == TPG_CENTER || yloc[f] == TPG_FACE);
-        if (aligned && nfields >= 1 && !(rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft))) {
+        && fields && xloc && yloc && sign && nfields >= 1 && (long long)Nz * (Nx + 2 * Hx) < (1ll << 31) - 256) {
+        bool valid = true;
+        for (int f = 0; f < nfields && valid; ++f)
+            valid = fields[f] && (xloc[f] == TPG_CENTER || xloc[f] == TPG_FACE) && (yloc[f] == TPG_CENTER || yloc[f] == TPG_FACE);
+        if (valid && !(rc = tpg::check_geom(Nx, Ny, Nz, Hx, Hy, Hz, ft))) {
             Geom g = tpg::make_geom(Nx, Ny, Nz, Hx, Hy, Hz);
-            MergedArgs a{ Nx, Ny, Hx, Hy, Hz, Nz, g.sx, g.sy, g.plane, g.sx / W, Hx / W, 0, (long long)g.sy * (Nz + 2 * Hz) };
+            // one plan for the whole call (all batches)
+            const ChunkPlan cp = ft == TPG_F64 ? chunk_plan<double>(g, fields, nfields) : chunk_plan<float>(g, fields, nfields);
+            const int W = cp.W, r = cp.gen ? Hx % W : 0;
+            MergedArgs a{ Nx, Ny, Hx, Hy, Hz, Nz, g.sx, g.sy, g.plane, cp.gen ? 2 * (Hx / W) + Nx / W : g.sx / W, cp.gen ? Hx : Hx / W, 0,
+                          (long long)g.sy * (Nz + 2 * Hz), r, (unsigned)(((long long)Nz * 2 * r + 255) / 256) };
             a.blocksA = (unsigned)(((long long)Nz * a.cprA + 255) / 256);
             hipStream_t s = tpg::as_stream(stream);
             for (int f0 = 0; f0 < nfields; f0 += TPG_MAX_FIELDS) {
@@ -195,12 +197,13 @@ int tpg_fill_halo_regions(void* const fields[], int nfields, const int8_t xloc[]
                 t.nfields = n;
                 for (int f = 0; f < n; ++f) { t.ptr[f] = fields[f0 + f]; t.xloc[f] = xloc[f0 + f]; t.yloc[f] = yloc[f0 + f]; t.sign[f] = sign[f0 + f]; t.item0[f] = 0; }
                 t.item0[n] = 0;
-                rc = (ft == TPG_F64) ? merged_batch<double, 2>(t, a, n, Hy, s) : merged_batch<float, 4>(t, a, n, Hy, s);
+                rc = (ft == TPG_F64) ? merged_dispatch<double>(t, a, n, Hy, cp, s) : merged_dispatch<float>(t, a, n, Hy, cp, s);
                 if (rc) return rc;
             }
             return TPG_OK;
         }
     }
+    rc = TPG_OK;
     if (north_is_zipper)
         rc = tpg_zipper_fill(fields, nfields, xloc, yloc, sign, Nx, Ny, Nz, Hx, Hy, Hz, 1, Nz, ft, stream);
     if (rc) return rc;

@@ -5,6 +5,7 @@
 #pragma once
 #include "tpg_common.hpp"
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 namespace tpg {
 // optional per-launch device timestamps (hipExtLaunchKernelGGL start / stop events): set by the *_timed entry points for
@@ -43,6 +44,41 @@ template <> struct Vec<float, 4> {
     typedef float aligned_t __attribute__((ext_vector_type(4)));
     typedef float loose_t __attribute__((ext_vector_type(4), aligned(4)));
 };
+// 8-B chunks: Float32 rows with Nx = 2 mod 4 do not split into 16-B chunks (GEN form only)
+template <> struct Vec<float, 2> {
+    typedef float aligned_t __attribute__((ext_vector_type(2)));
+    typedef float loose_t __attribute__((ext_vector_type(2), aligned(4)));
+};
+
+// ---- GEN = true: chunks aligned with the INTERIOR, not with the parent ---------------------------------------------------------------
+// The reference's model examples run halo = (5, 5, 5) (examples/bickley_jet.jl:21, examples/distributed_bickley_jet.jl:23): with an odd Hx
+// the interior columns of a Float64 parent row start 8 B off the 16-B grid, and so do all its W-element chunks counted from i = 1.  The
+// chunked kernels keep exactly their chunking -- chunk c of the interior is i = cW+1 .. cW+W, the x-halo chunks continue it outwards -- and
+// only change the ACCESS TYPE: stores and the row-Ny / periodic loads go through the element-aligned `loose_t` (a 16-B access on an 8-B
+// boundary), as the mirrored x-Face windows always did.  Measured on 3600 x 1800 x 75, 4 fields: the fold with such stores takes 17.8 us at
+// halo 5 (90.7 MB) against 14.9 us at halo 4 (73.4 MB) -- 0.96 of the halo-4 time per byte -- and 17.6-17.8 us with parent-aligned chunks
+// and element-wise edge chunks (profiles/r06/halo5_periodic_variants.json): alignment of the stores buys nothing, uniform waves do.
+// What does not fit a chunk is the r = Hx mod W outermost columns of each x halo (r = 1 at halo 5): the composed-map kernels give them
+// element items of their own (S items: blocks / item ranges apart from the chunk items, so that no wave runs both code paths).
+// GEN also serves 16-B-misaligned field pointers (any element-aligned pointer works) and Float32 rows with Nx = 2 mod 4 (W = 2).
+// GEN = false is the geometry the kernels had before (Hx, Nx multiples of W, 16-B aligned fields) and compiles to the code it was.
+// The PERIODIC part of a GEN fill (the rows below the fold; tpg_periodic_x_fill) is one element per item -- item (row, h) copies
+// c[Nx+h] -> c[h] and c[Hx+h] -> c[Hx+Nx+h] --, which measured best at halo 5 (one merged launch, 4 fields, cold): element items 62.7-63.6 us;
+// 3 uniform 16-B items per row, the third overlapping the second by one element, 63.2-63.4 us; aligned 16-B items + one leftover item (a
+// divergent wave: two dependent memory round trips) 81-82 us; one item per (row, side) 105 us; one item per row 91 us.  The pass is bound by
+// 128-B line transfers (2.1 lines per row at this pitch, 1.5 at halo 4): the finest uniform items keep the most requests in flight.
+
+// composed map of ONE written cell at parent column ii: wrapped column iw (1..Nx), mirrored source column ip (1..Nx), factor se
+// (x-Center i' = Nx-iw+1; x-Face i' = Nx-iw+2, iw = 1 wrapping to i' = 1 with |sign|: zipper_boundary_condition.jl:73-75, :90-92)
+template <typename T>
+__device__ __forceinline__ void fold_column(int ii, int Nx, int Hx, int xl, T s, T as, int& iw, int& ip, T& se)
+{
+    const int i = ii - Hx + 1;
+    iw = i < 1 ? i + Nx : (i > Nx ? i - Nx : i);
+    ip = Nx - iw + 1 + (xl == TPG_FACE ? 1 : 0);
+    se = s;
+    if (ip > Nx) { ip -= Nx; se = as; }
+}
 
 __device__ __forceinline__ int find_field(const FieldTable& ft, int item)
 {
@@ -123,11 +159,13 @@ __global__ __launch_bounds__(256) void k_zipper_vec(FieldTable ft, ZipArgs a)
 // caches full of dirty lines costs 17.7 instead of 23.6 us that way; stores are plain (tools/fillbench).
 // COPY = true is the bench's same-shape copy ceiling (tpg_zipper_copy_probe): identical rows, bytes and launch
 // shape, but destination column = source column and no sign.
-template <typename T, int W, int HY, bool COPY>
+template <typename T, int W, int HY, bool COPY, bool GEN = false>
 __global__ __launch_bounds__(256) void k_zipper_cols(FieldTable ft, ZipArgs a)
 {
+    static_assert(!(COPY && GEN), "the copy probe exists for the chunk-aligned geometry only");
     typedef typename Vec<T, W>::aligned_t vec_t;
     typedef typename Vec<T, W>::loose_t lvec_t;
+    typedef typename std::conditional<GEN, lvec_t, vec_t>::type svec_t;   // destination chunks: 16-B aligned, or (GEN) element-aligned
     const int f = blockIdx.y;                                      // wave-uniform: table reads are scalar loads
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= a.kcount * a.nchunks) return;
@@ -162,7 +200,7 @@ __global__ __launch_bounds__(256) void k_zipper_cols(FieldTable ft, ZipArgs a)
     if (fix) {
         vf = *reinterpret_cast<const lvec_t*>(lvl + sx * prow_ny + soff);
         if (i <= a.Nx / 2)       // only the chunk that straddles Nx/2 keeps part of the old row
-            old = *reinterpret_cast<const vec_t*>(lvl + sx * prow_ny + (i - 1));
+            old = *reinterpret_cast<const svec_t*>(lvl + sx * prow_ny + (i - 1));
     }
     const T s = (T)sgn, as = (T)(sgn < 0 ? -sgn : sgn);
 #pragma unroll
@@ -171,14 +209,14 @@ __global__ __launch_bounds__(256) void k_zipper_cols(FieldTable ft, ZipArgs a)
 #pragma unroll
         for (int e = 0; e < W; ++e) o[e] = COPY ? v[jr - 1][e] : s * v[jr - 1][W - 1 - e];
         if (wrap) o[0] = as * w0[jr - 1];
-        *reinterpret_cast<vec_t*>(lvl + sx * (prow_ny + jr) + (i - 1)) = o;
+        *reinterpret_cast<svec_t*>(lvl + sx * (prow_ny + jr) + (i - 1)) = o;
     }
     if (fix) {
         // c[i,Ny] = ifelse(i > Nx/2, sign*c[i',Ny], c[i,Ny]) (:102,:135); i = 1 is never > Nx/2
         vec_t o;
 #pragma unroll
         for (int e = 0; e < W; ++e) o[e] = (i + e > a.Nx / 2) ? (COPY ? vf[e] : s * vf[W - 1 - e]) : old[e];
-        *reinterpret_cast<vec_t*>(lvl + sx * prow_ny + (i - 1)) = o;
+        *reinterpret_cast<svec_t*>(lvl + sx * prow_ny + (i - 1)) = o;
     }
 }
 
@@ -312,13 +350,17 @@ __global__ __launch_bounds__(256) void k_fill_fused(FieldTable ft, FusedArgs a)
 // W elements share one wrapped base column iw0 and its mirrored source is ONE contiguous, reversed window.
 //   items of a level:  A = (Hy+1) rows from row Ny up  x  sx/W chunks (all columns, corners included)
 //                      B = the Ny+Hy-1 rows below       x  2Hx/W x-halo chunks (plain periodic copies)
-struct FusedVecArgs { int Nx, Ny, Hx, Hy, Hz, Nz, sx; long long plane; int cpr, hc, itemsA, per_level; };
+// GEN = true (see the note on GEN above): the chunks of A start at parent column r = Hx mod W (cpr = 2 (Hx / W) + Nx / W of them, all whole)
+// and are stored element-aligned; the 2 r outermost halo columns of the (Hy+1) rows are S items, itemsA <= item < itemsA + itemsS, one
+// element each through the scalar composed map; B has hc = Hx items per row, one element of each side per item.
+struct FusedVecArgs { int Nx, Ny, Hx, Hy, Hz, Nz, sx; long long plane; int cpr, hc, itemsA, per_level; int r, itemsS; };
 
-template <typename T, int W>
+template <typename T, int W, bool GEN = false>
 __global__ __launch_bounds__(256) void k_fill_fused_vec(FieldTable ft, FusedVecArgs a)
 {
     typedef typename Vec<T, W>::aligned_t vec_t;
     typedef typename Vec<T, W>::loose_t lvec_t;
+    typedef typename std::conditional<GEN, lvec_t, vec_t>::type svec_t;   // destination chunks and their periodic sources: aligned, or (GEN) element-aligned
     const int f = blockIdx.y;
     int item = blockIdx.x * blockDim.x + threadIdx.x;
     const int nlev = a.Nz + 2 * a.Hz;
@@ -326,10 +368,36 @@ __global__ __launch_bounds__(256) void k_fill_fused_vec(FieldTable ft, FusedVecA
     const int lev = item / a.per_level;
     item -= lev * a.per_level;
     T* c = static_cast<T*>(ft.ptr[f]) + a.plane * lev;
+    if constexpr (GEN) {
+        if (item >= a.itemsA && item < a.itemsA + a.itemsS) {
+            // ---- S: one of the r outermost columns of the west / east halo, rows Ny .. Ny+Hy: the composed map for one cell
+            item -= a.itemsA;
+            const int jr = item / (2 * a.r), q = item - jr * 2 * a.r;
+            const int ii = q < a.r ? q : a.sx - 2 * a.r + q;          // west: columns 0 .. r-1; east: sx-r .. sx-1
+            const int xl = ft.xloc[f], yl = ft.yloc[f], sgn = ft.sign[f];
+            const bool zipped = lev >= a.Hz && lev < a.Hz + a.Nz;
+            T* rowNy = c + (long long)a.sx * (a.Ny + a.Hy - 1);
+            T* drow = rowNy + (long long)a.sx * jr;
+            int iw, ip; T se;
+            fold_column(ii, a.Nx, a.Hx, xl, (T)sgn, (T)(sgn < 0 ? -sgn : sgn), iw, ip, se);
+            if (zipped && jr > 0) drow[ii] = se * rowNy[(ip + a.Hx - 1) - (long long)a.sx * (jr - (yl == TPG_FACE ? 1 : 0))];
+            else if (zipped && yl == TPG_CENTER && iw > a.Nx / 2) drow[ii] = se * rowNy[ip + a.Hx - 1];            // row Ny (:102, :135)
+            else drow[ii] = drow[iw + a.Hx - 1];                                                                  // plain periodic copy
+            return;
+        }
+        if (item >= a.itemsA) item -= a.itemsS;
+    }
     if (item >= a.itemsA) {
         // ---- B: x-halo chunk of a row below row Ny: west halo <- east interior columns, east halo <- west interior
         item -= a.itemsA;
         const int jj = item / a.hc, q = item - jj * a.hc;
+        if constexpr (GEN) {                                        // one element of each side per item: hc = Hx
+            T* r = c + (long long)a.sx * jj;
+            const T w = r[a.Nx + q], e = r[a.Hx + q];
+            r[q] = w;
+            r[a.Hx + a.Nx + q] = e;
+            return;
+        }
         const int hw = a.hc >> 1;                                   // chunks per halo side
         T* row = c + (long long)a.sx * jj;
         const int dst = q < hw ? q * W : a.Hx + a.Nx + (q - hw) * W;
@@ -341,7 +409,7 @@ __global__ __launch_bounds__(256) void k_fill_fused_vec(FieldTable ft, FusedVecA
     const int xl = ft.xloc[f], yl = ft.yloc[f];
     const int sgn = ft.sign[f];
     const int jr = item / a.cpr, ch = item - jr * a.cpr;            // jr = 0: row Ny, 1..Hy: halo rows
-    const int ii0 = ch * W;                                         // parent column of the chunk's first element
+    const int ii0 = (GEN ? a.r : 0) + ch * W;                       // parent column of the chunk's first element
     const int i = ii0 - a.Hx + 1;                                   // its logical column
     const bool west = ii0 < a.Hx, east = ii0 >= a.Hx + a.Nx;
     const int iw0 = west ? i + a.Nx : (east ? i - a.Nx : i);        // wrapped into 1..Nx (whole chunk: Hx % W == 0)
@@ -369,14 +437,14 @@ __global__ __launch_bounds__(256) void k_fill_fused_vec(FieldTable ft, FusedVecA
         if (!any_hi && !halo) return;
         vec_t v = {}, pl = {};
         if (any_hi) v = *reinterpret_cast<const lvec_t*>(rowNy + wlo);
-        if (any_lo) pl = *reinterpret_cast<const vec_t*>(rowNy + (iw0 + a.Hx - 1));
+        if (any_lo) pl = *reinterpret_cast<const svec_t*>(rowNy + (iw0 + a.Hx - 1));
 #pragma unroll
         for (int e = 0; e < W; ++e) o[e] = (iw0 + e > a.Nx / 2) ? s * v[W - 1 - e] : pl[e];
     } else {
         if (!halo) return;                                          // z-halo level, or row Ny of a y-Face field: periodic x only
-        o = *reinterpret_cast<const vec_t*>(drow + (iw0 + a.Hx - 1));
+        o = *reinterpret_cast<const svec_t*>(drow + (iw0 + a.Hx - 1));
     }
-    *reinterpret_cast<vec_t*>(drow + ii0) = o;
+    *reinterpret_cast<svec_t*>(drow + ii0) = o;
 }
 
 
@@ -388,23 +456,59 @@ __global__ __launch_bounds__(256) void k_fill_fused_vec(FieldTable ft, FusedVecA
 // Blocks [blocksA, ..): the periodic pass of every other (level, row): all rows of the z-halo levels, rows below row Ny of
 // the folded levels.  The two parts touch disjoint cells and read only interior cells nobody writes, so they need no order: one kernel boundary less per fill, and the fold's launch
 // ramp and tail hide under the periodic pass's stream.  Same geometry conditions as k_fill_fused.
-struct MergedArgs { int Nx, Ny, Hx, Hy, Hz, Nz, sx, sy; long long plane; int cprA, hw; unsigned blocksA; long long rowsB; };
+// GEN = true (see the note on GEN above; the reference's model halo (5, 5, 5)): the chunks of A start at parent column r = Hx mod W
+// (cprA = 2 (Hx / W) + Nx / W per level, all whole) and are stored element-aligned; blocks [blocksA, blocksA + blocksS) are the S items --
+// one thread per (level, one of the 2 r outermost halo columns), rows Ny .. Ny+Hy through the scalar composed map --; in B a.hw = Hx items
+// per row, one element of each side per item.
+struct MergedArgs { int Nx, Ny, Hx, Hy, Hz, Nz, sx, sy; long long plane; int cprA, hw; unsigned blocksA; long long rowsB; int r; unsigned blocksS; };
 
-template <typename T, int W, int HY>
+template <typename T, int W, int HY, bool GEN = false>
 __global__ __launch_bounds__(256) void k_fill_merged(FieldTable ft, MergedArgs a)
 {
     typedef typename Vec<T, W>::aligned_t vec_t;
     typedef typename Vec<T, W>::loose_t lvec_t;
+    typedef typename std::conditional<GEN, lvec_t, vec_t>::type svec_t;   // destination chunks and their periodic sources: aligned, or (GEN) element-aligned
     const int f = blockIdx.y;
     T* __restrict__ c = static_cast<T*>(ft.ptr[f]);
+    if constexpr (GEN) {
+        if (blockIdx.x >= a.blocksA && blockIdx.x < a.blocksA + a.blocksS) {
+            // ---- S: one of the r outermost columns of the west / east halo of one level, rows Ny .. Ny+Hy
+            const int item = (blockIdx.x - a.blocksA) * 256 + threadIdx.x;
+            if (item >= a.Nz * 2 * a.r) return;
+            const int kk = item / (2 * a.r), q = item - kk * 2 * a.r;
+            const int ii = q < a.r ? q : a.sx - 2 * a.r + q;          // west: columns 0 .. r-1; east: sx-r .. sx-1
+            const int xl = ft.xloc[f], yl = ft.yloc[f], sgn = ft.sign[f];
+            const long long sx = a.sx;
+            T* rowNy = c + a.plane * (kk + a.Hz) + sx * (a.Ny + a.Hy - 1);
+            const int ysh = (yl == TPG_FACE) ? 1 : 0;
+            int iw, ip; T se;
+            fold_column(ii, a.Nx, a.Hx, xl, (T)sgn, (T)(sgn < 0 ? -sgn : sgn), iw, ip, se);
+            T q0, qv[HY];
+#pragma unroll
+            for (int jr = 1; jr <= HY; ++jr) qv[jr - 1] = rowNy[(ip + a.Hx - 1) - sx * (jr - ysh)];
+            const bool fixed = yl == TPG_CENTER && iw > a.Nx / 2;      // (:102, :135): the periodic image of the substituted cell
+            q0 = fixed ? rowNy[ip + a.Hx - 1] : rowNy[iw + a.Hx - 1];
+#pragma unroll
+            for (int jr = 1; jr <= HY; ++jr) rowNy[sx * jr + ii] = se * qv[jr - 1];
+            rowNy[ii] = fixed ? se * q0 : q0;
+            return;
+        }
+    }
     if (blockIdx.x >= a.blocksA) {
         // ---- B: periodic x of one (level, row): chunk v of the west halo and of the east halo
-        const long long item = (long long)(blockIdx.x - a.blocksA) * 256 + threadIdx.x;
+        const long long item = (long long)(blockIdx.x - a.blocksA - (GEN ? a.blocksS : 0u)) * 256 + threadIdx.x;
         if (item >= a.rowsB * a.hw) return;
         const long long row = item / a.hw;                          // over (level, parent row)
         const int v = (int)(item - row * a.hw);
         const int lev = (int)(row / a.sy), jj = (int)(row - (long long)lev * a.sy);
         if (lev >= a.Hz && lev < a.Hz + a.Nz && jj >= a.Ny + a.Hy - 1) return;      // rows Ny.. of a folded level: part A
+        if constexpr (GEN) {                                        // one element of each side per item: a.hw = Hx
+            T* r = c + row * a.sx;
+            const T w = r[a.Nx + v], e = r[a.Hx + v];
+            r[v] = w;
+            r[a.Hx + a.Nx + v] = e;
+            return;
+        }
         vec_t* r = reinterpret_cast<vec_t*>(c + row * a.sx);
         const int nxc = a.Nx / W, hxc = a.Hx / W;
         const vec_t w = r[nxc + v], e = r[hxc + v];
@@ -418,7 +522,7 @@ __global__ __launch_bounds__(256) void k_fill_merged(FieldTable ft, MergedArgs a
     const int xl = ft.xloc[f], yl = ft.yloc[f];
     const int sgn = ft.sign[f];
     const int kk = item / a.cprA, ch = item - kk * a.cprA;
-    const int ii0 = ch * W;                                         // parent column of the chunk
+    const int ii0 = (GEN ? a.r : 0) + ch * W;                       // parent column of the chunk
     const int i = ii0 - a.Hx + 1;
     const bool west = ii0 < a.Hx, east = ii0 >= a.Hx + a.Nx;
     const int iw0 = west ? i + a.Nx : (east ? i - a.Nx : i);        // wrapped into 1..Nx
@@ -444,7 +548,7 @@ __global__ __launch_bounds__(256) void k_fill_merged(FieldTable ft, MergedArgs a
     const bool need_pl = (yl == TPG_CENTER) ? ((iw0 <= a.Nx / 2) && (halo || any_hi)) : halo;
     vec_t vf = {}, pl = {};
     if (any_hi) vf = *reinterpret_cast<const lvec_t*>(rowNy + wlo);
-    if (need_pl) pl = *reinterpret_cast<const vec_t*>(rowNy + (iw0 + a.Hx - 1));
+    if (need_pl) pl = *reinterpret_cast<const svec_t*>(rowNy + (iw0 + a.Hx - 1));
     const T s = (T)sgn, as = (T)(sgn < 0 ? -sgn : sgn);
 #pragma unroll
     for (int jr = 1; jr <= HY; ++jr) {
@@ -452,13 +556,13 @@ __global__ __launch_bounds__(256) void k_fill_merged(FieldTable ft, MergedArgs a
         o[0] = wrap ? as * w0[jr - 1] : s * v[jr - 1][W - 1];
 #pragma unroll
         for (int e = 1; e < W; ++e) o[e] = s * (wrap ? v[jr - 1][W - e] : v[jr - 1][W - 1 - e]);
-        *reinterpret_cast<vec_t*>(rowNy + sx * jr + ii0) = o;
+        *reinterpret_cast<svec_t*>(rowNy + sx * jr + ii0) = o;
     }
     if (any_hi || need_pl) {
         vec_t o;
 #pragma unroll
         for (int e = 0; e < W; ++e) o[e] = (any_hi && iw0 + e > a.Nx / 2) ? s * vf[W - 1 - e] : pl[e];
-        *reinterpret_cast<vec_t*>(rowNy + ii0) = o;
+        *reinterpret_cast<svec_t*>(rowNy + ii0) = o;
     }
 }
 
@@ -499,45 +603,63 @@ int check_fields(void* const fields[], int nfields)
             hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                    \
     } while (0)
 
-template <typename T, int W, bool COPY>
+// Which instantiation of the chunked kernels serves this geometry and these pointers.  Plain (gen = false): Hx and Nx whole numbers of
+// 16-B chunks and every field 16-B aligned -- the geometry of the defaults, halo (4, 4, 4).  GEN (see the note above) for everything else:
+// an odd Hx (the reference's model halo (5, 5, 5)), 16-B-misaligned pointers, and -- with 8-B chunks, W = 2 -- Float32 rows with
+// Nx = 2 mod 4.  Nx is even (tripolar_grid.jl:81-83), so W = 2 always divides it: every geometry has a chunked form.
+struct ChunkPlan { int W; bool gen; };
+template <typename T>
+ChunkPlan chunk_plan(const Geom& g, void* const fields[], int n)
+{
+    constexpr int WMAX = 16 / (int)sizeof(T);
+    bool plain = g.Hx % WMAX == 0 && g.Nx % WMAX == 0;
+    for (int f = 0; f < n && plain; ++f) plain = ((uintptr_t)fields[f] % 16) == 0;
+    if (plain) return { WMAX, false };
+    return { g.Nx % WMAX == 0 ? WMAX : 2, true };
+}
+
+template <typename T, int W, bool COPY, bool GEN>
 void launch_cols(int Hy, dim3 grid, hipStream_t s, const FieldTable& ft, const ZipArgs& a)
 {
     switch (Hy) {
-    case 1: TPG_LAUNCH((k_zipper_cols<T, W, 1, COPY>), grid, dim3(256), s, ft, a); break;
-    case 2: TPG_LAUNCH((k_zipper_cols<T, W, 2, COPY>), grid, dim3(256), s, ft, a); break;
-    case 3: TPG_LAUNCH((k_zipper_cols<T, W, 3, COPY>), grid, dim3(256), s, ft, a); break;
-    case 4: TPG_LAUNCH((k_zipper_cols<T, W, 4, COPY>), grid, dim3(256), s, ft, a); break;
-    case 5: TPG_LAUNCH((k_zipper_cols<T, W, 5, COPY>), grid, dim3(256), s, ft, a); break;
-    case 6: TPG_LAUNCH((k_zipper_cols<T, W, 6, COPY>), grid, dim3(256), s, ft, a); break;
-    case 7: TPG_LAUNCH((k_zipper_cols<T, W, 7, COPY>), grid, dim3(256), s, ft, a); break;
-    default: TPG_LAUNCH((k_zipper_cols<T, W, 8, COPY>), grid, dim3(256), s, ft, a); break;
+    case 1: TPG_LAUNCH((k_zipper_cols<T, W, 1, COPY, GEN>), grid, dim3(256), s, ft, a); break;
+    case 2: TPG_LAUNCH((k_zipper_cols<T, W, 2, COPY, GEN>), grid, dim3(256), s, ft, a); break;
+    case 3: TPG_LAUNCH((k_zipper_cols<T, W, 3, COPY, GEN>), grid, dim3(256), s, ft, a); break;
+    case 4: TPG_LAUNCH((k_zipper_cols<T, W, 4, COPY, GEN>), grid, dim3(256), s, ft, a); break;
+    case 5: TPG_LAUNCH((k_zipper_cols<T, W, 5, COPY, GEN>), grid, dim3(256), s, ft, a); break;
+    case 6: TPG_LAUNCH((k_zipper_cols<T, W, 6, COPY, GEN>), grid, dim3(256), s, ft, a); break;
+    case 7: TPG_LAUNCH((k_zipper_cols<T, W, 7, COPY, GEN>), grid, dim3(256), s, ft, a); break;
+    default: TPG_LAUNCH((k_zipper_cols<T, W, 8, COPY, GEN>), grid, dim3(256), s, ft, a); break;
     }
 }
 
-// Kernel choice: column items (k_zipper_cols) wherever rows are 16-B chunkable and Hy <= 8; row items otherwise
-// (k_zipper_vec for Hy > 8 -- e.g. the extended north halo of the split-explicit free surface --, k_zipper_scalar for
-// odd Hx / misaligned pointers).  TPG_ZIPPER_VARIANT=0 forces the row kernels everywhere (cross-check,
+// Kernel choice: column items (k_zipper_cols, plain or GEN: chunk_plan) for Hy <= 8; row items otherwise
+// (k_zipper_vec for Hy > 8 -- e.g. the extended north halo of the split-explicit free surface -- on the plain geometry, k_zipper_scalar
+// for Hy > 8 elsewhere and for Hy = 0).  TPG_ZIPPER_VARIANT=0 forces the row kernels everywhere (cross-check,
 // tests/test_gpu_variants.py).  What was measured and dropped (tools/fillbench, profiles/r02/fillbench_ab.txt):
 // plain loads (cold-dirty 26 vs 20 us), non-temporal stores (+2 us), write-through sc1 / sc0 sc1 buffer stores
 // (-0.5 us cold-clean, +0 dirty), a persistent software-pipelined grid (1024 blocks, loads of item n+1 ahead of the
 // stores of item n: -0.5 us), two half-row chunks per thread (one resident round of 4224 waves: +-0), 512 / 1024-thread
 // blocks, two levels per thread (slower).  All of them, and same-shape pure copies, sit at 14.7-16.1 us cold:
 // the 73 MB launch is at the copy ceiling of this access shape.
-template <typename T, int W, bool COPY = false>
+template <typename T, bool COPY = false>
 int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                  const Geom& g, int kstart, int kcount, hipStream_t s)
 {
-    bool vec = (g.Hx % W == 0) && (g.Nx % W == 0);
-    for (int f = 0; f < n && vec; ++f) vec = ((uintptr_t)fields[f] % 16) == 0;
-    const bool cols = vec && g.Hy >= 1 && g.Hy <= 8 && (COPY || tpg::config().zipper_variant != 0);    // Hy = 0: only the row-Ny substitution remains (row kernels)
-    if (COPY && !cols) { tpg::set_error("copy probe: geometry has no column kernel"); return TPG_ERR_UNSUPPORTED; }
+    constexpr int WMAX = 16 / (int)sizeof(T);
+    const ChunkPlan cp = chunk_plan<T>(g, fields, n);
+    const int W = cp.W;
+    const bool vec = !cp.gen;                                        // the row-item kernel k_zipper_vec exists in the plain form only
+    const bool cols = g.Hy >= 1 && g.Hy <= 8 && (COPY ? vec : tpg::config().zipper_variant != 0);    // Hy = 0: only the row-Ny substitution remains (row kernels)
+    if (COPY && !cols) { tpg::set_error("copy probe: geometry has no plain column kernel"); return TPG_ERR_UNSUPPORTED; }
 
     FieldTable ft;
     ZipArgs a;
     a.Nx = g.Nx; a.Ny = g.Ny; a.Hx = g.Hx; a.Hy = g.Hy; a.Hz = g.Hz; a.sx = g.sx; a.plane = g.plane;
     a.kstart = kstart; a.kcount = kcount;
-    a.nchunks = vec ? g.Nx / W : g.Nx;
-    a.fix0 = vec ? (g.Nx / 2) / W : g.Nx / 2;      // first chunk / element (0-based) holding an i > Nx/2
+    const bool chunked = cols || vec;
+    a.nchunks = chunked ? g.Nx / W : g.Nx;
+    a.fix0 = chunked ? (g.Nx / 2) / W : g.Nx / 2;      // first chunk / element (0-based) holding an i > Nx/2
     ft.nfields = n;
     long long total = 0;
     for (int f = 0; f < n; ++f) {
@@ -553,29 +675,60 @@ int zipper_batch(void* const fields[], int n, const int8_t xloc[], const int8_t 
     dim3 grid((unsigned)((total + 255) / 256));
     if (cols) {
         dim3 grid2((unsigned)(((long long)kcount * a.nchunks + 255) / 256), (unsigned)n);
-        launch_cols<T, W, COPY>(g.Hy, grid2, s, ft, a);
+        if constexpr (COPY) {
+            launch_cols<T, WMAX, true, false>(g.Hy, grid2, s, ft, a);
+        } else if constexpr (sizeof(T) == 8) {
+            if (cp.gen) launch_cols<T, 2, false, true>(g.Hy, grid2, s, ft, a);
+            else        launch_cols<T, 2, false, false>(g.Hy, grid2, s, ft, a);
+        } else {
+            if (W == 2)      launch_cols<T, 2, false, true>(g.Hy, grid2, s, ft, a);
+            else if (cp.gen) launch_cols<T, 4, false, true>(g.Hy, grid2, s, ft, a);
+            else             launch_cols<T, 4, false, false>(g.Hy, grid2, s, ft, a);
+        }
     }
-    else if (vec) TPG_LAUNCH((k_zipper_vec<T, W>), grid, dim3(256), s, ft, a);
+    else if (vec) TPG_LAUNCH((k_zipper_vec<T, WMAX>), grid, dim3(256), s, ft, a);
     else          TPG_LAUNCH((k_zipper_scalar<T>), grid, dim3(256), s, ft, a);
     return tpg::launch_status("k_zipper");
 }
 
-template <typename T, int W>
+template <typename T, int W, bool GEN>
 int merged_batch(const FieldTable& t, const MergedArgs& a, int n, int Hy, hipStream_t s)
 {
     const long long itemsB = a.rowsB * a.hw;
-    dim3 grid(a.blocksA + (unsigned)((itemsB + 255) / 256), (unsigned)n);
+    dim3 grid(a.blocksA + a.blocksS + (unsigned)((itemsB + 255) / 256), (unsigned)n);
     switch (Hy) {
-    case 1: TPG_LAUNCH((k_fill_merged<T, W, 1>), grid, dim3(256), s, t, a); break;
-    case 2: TPG_LAUNCH((k_fill_merged<T, W, 2>), grid, dim3(256), s, t, a); break;
-    case 3: TPG_LAUNCH((k_fill_merged<T, W, 3>), grid, dim3(256), s, t, a); break;
-    case 4: TPG_LAUNCH((k_fill_merged<T, W, 4>), grid, dim3(256), s, t, a); break;
-    case 5: TPG_LAUNCH((k_fill_merged<T, W, 5>), grid, dim3(256), s, t, a); break;
-    case 6: TPG_LAUNCH((k_fill_merged<T, W, 6>), grid, dim3(256), s, t, a); break;
-    case 7: TPG_LAUNCH((k_fill_merged<T, W, 7>), grid, dim3(256), s, t, a); break;
-    default: TPG_LAUNCH((k_fill_merged<T, W, 8>), grid, dim3(256), s, t, a); break;
+    case 1: TPG_LAUNCH((k_fill_merged<T, W, 1, GEN>), grid, dim3(256), s, t, a); break;
+    case 2: TPG_LAUNCH((k_fill_merged<T, W, 2, GEN>), grid, dim3(256), s, t, a); break;
+    case 3: TPG_LAUNCH((k_fill_merged<T, W, 3, GEN>), grid, dim3(256), s, t, a); break;
+    case 4: TPG_LAUNCH((k_fill_merged<T, W, 4, GEN>), grid, dim3(256), s, t, a); break;
+    case 5: TPG_LAUNCH((k_fill_merged<T, W, 5, GEN>), grid, dim3(256), s, t, a); break;
+    case 6: TPG_LAUNCH((k_fill_merged<T, W, 6, GEN>), grid, dim3(256), s, t, a); break;
+    case 7: TPG_LAUNCH((k_fill_merged<T, W, 7, GEN>), grid, dim3(256), s, t, a); break;
+    default: TPG_LAUNCH((k_fill_merged<T, W, 8, GEN>), grid, dim3(256), s, t, a); break;
     }
     return tpg::launch_status("k_fill_merged");
+}
+
+// the (T, W, GEN) instantiations that exist: Float64 16-B chunks plain / GEN; Float32 16-B chunks plain / GEN, 8-B chunks GEN only
+template <typename T>
+int merged_dispatch(const FieldTable& t, const MergedArgs& a, int n, int Hy, ChunkPlan cp, hipStream_t s)
+{
+    if constexpr (sizeof(T) == 8) return cp.gen ? merged_batch<T, 2, true>(t, a, n, Hy, s) : merged_batch<T, 2, false>(t, a, n, Hy, s);
+    else if (cp.W == 2) return merged_batch<T, 2, true>(t, a, n, Hy, s);
+    else return cp.gen ? merged_batch<T, 4, true>(t, a, n, Hy, s) : merged_batch<T, 4, false>(t, a, n, Hy, s);
+}
+
+template <typename T>
+void fused_vec_dispatch(dim3 grid, hipStream_t s, const FieldTable& t, const FusedVecArgs& v, ChunkPlan cp)
+{
+    if constexpr (sizeof(T) == 8) {
+        if (cp.gen) TPG_LAUNCH((k_fill_fused_vec<T, 2, true>), grid, dim3(256), s, t, v);
+        else        TPG_LAUNCH((k_fill_fused_vec<T, 2, false>), grid, dim3(256), s, t, v);
+    } else {
+        if (cp.W == 2)   TPG_LAUNCH((k_fill_fused_vec<T, 2, true>), grid, dim3(256), s, t, v);
+        else if (cp.gen) TPG_LAUNCH((k_fill_fused_vec<T, 4, true>), grid, dim3(256), s, t, v);
+        else             TPG_LAUNCH((k_fill_fused_vec<T, 4, false>), grid, dim3(256), s, t, v);
+    }
 }
 
 }  // namespace

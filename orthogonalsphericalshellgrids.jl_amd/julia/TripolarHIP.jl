@@ -276,27 +276,49 @@ const DTRG = Union{DistributedTripolarGrid, ImmersedBoundaryGrid{<:Any, <:Any, <
 # The 1-D tables tpg_build_grid leaves in its workspace, kept for later builds of the same geometry (TPG_BUILD_TABLES_VALID,
 # include/tripolar_hip.h): `key` = exactly what the tables depend on -- global Nx, Ny, Hy, element type, southernmost latitude,
 # north-poles latitude, radius -- plus the architecture; jstart / jend, Hx, Hz, Nz and first_pole_longitude do not enter.  A workspace
-# lives as long as a grid built on it: GRID_WORKSPACES is weak in its keys (the grid's lambda_cc parent array), so with_halo (same size,
-# new Hx / Hz: src/with_halo.jl:5-44), reconstruct_global_grid after a band build (src/distributed_tripolar_grid.jl:201-226) and
-# consecutive band builds of one geometry find the tables of the first build, and nothing outlives the grids.  A build whose key differs
-# gets a NEW workspace: the tables of a live grid are never overwritten.
+# lives as long as a grid built on it: GRID_WORKSPACES holds (WeakRef(the grid's lambda_cc parent array), workspace) entries, so with_halo
+# (same size, new Hx / Hz: src/with_halo.jl:5-44), reconstruct_global_grid after a band build (src/distributed_tripolar_grid.jl:201-226)
+# and consecutive band builds of one geometry find the tables of the first build, and nothing outlives the grids.  A build whose key
+# differs gets a NEW workspace: the tables of a live grid are never overwritten.
+# The owner array is matched by IDENTITY (===) only: a dictionary keyed by a device array would hash / compare its ELEMENTS
+# (Base.hash(::AbstractArray) indexes them), which a HIPArray refuses (scalar indexing) and any device array makes a PCIe round trip.
 const TPG_BUILD_TABLES_VALID = Int32(1)
 mutable struct TableWorkspace
     key::Any
     buffer::Any                    # device array of tpg_build_grid_workspace_bytes
     stream::Ptr{Cvoid}             # the stream the table kernel ran on
 end
-const GRID_WORKSPACES = WeakKeyDict{Any, TableWorkspace}()
+struct WorkspaceOwner
+    owner::WeakRef                 # the grid's lambda_cc parent array: compared with === only, never hashed, never indexed
+    workspace::TableWorkspace
+end
+const GRID_WORKSPACES = WorkspaceOwner[]
 table_key(arch, FT, Nλ, Nφ, Hφ, south, npl, radius) = (serial_arch(arch), FT, Int(Nλ), Int(Nφ), Int(Hφ), Float64(south), Float64(npl), Float64(radius))
+"entries whose grid is gone leave the table (callers hold STATE_LOCK)"
+prune_workspaces!(table) = filter!(e -> e.owner.value !== nothing, table)
 function live_workspace(key, nbytes)
     lock(STATE_LOCK) do
-        for w in values(GRID_WORKSPACES)
-            w.key == key && sizeof(w.buffer) >= nbytes && return w
+        for e in prune_workspaces!(GRID_WORKSPACES)
+            e.workspace.key == key && sizeof(e.workspace.buffer) >= nbytes && return e.workspace
         end
         return nothing
     end
 end
-table_workspace(grid) = lock(() -> get(GRID_WORKSPACES, parent(grid.λᶜᶜᵃ), nothing), STATE_LOCK)
+function keep_workspace!(owner, ws::TableWorkspace)
+    lock(STATE_LOCK) do
+        push!(prune_workspaces!(GRID_WORKSPACES), WorkspaceOwner(WeakRef(owner), ws))
+    end
+    return ws
+end
+function table_workspace(grid)
+    a = parent(grid.λᶜᶜᵃ)
+    lock(STATE_LOCK) do
+        for e in GRID_WORKSPACES
+            e.owner.value === a && return e.workspace
+        end
+        return nothing
+    end
+end
 
 # ONE tpg_build_grid call fills the 20 padded arrays of the latitude band jstart:jend in HBM (no host passes, no H2D).
 function build_band(arch, FT, size, halo, southernmost_latitude, radius, z, north_poles_latitude, first_pole_longitude,
@@ -327,7 +349,7 @@ function build_band(arch, FT, size, halo, southernmost_latitude, radius, z, nort
                     (Ref{TpgParams}, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
                     p, ptrs, device_pointer(workspace), nbytes, s))
     end
-    lock(() -> (GRID_WORKSPACES[arrays[1]] = ws), STATE_LOCK)     # arrays[1] = parent of lambda_cc: the grid keeps its tables alive
+    keep_workspace!(arrays[1], ws)                                # arrays[1] = parent of lambda_cc: the grid keeps its tables alive
     # enum tpg_array == positional order of src/tripolar_grid.jl:308-328 (note dy: cc, cf, fc, ff)
     off(a) = OffsetArray(a, -Hλ, -Hφ)
     λcc, λfc, λcf, λff, φcc, φfc, φcf, φff,
@@ -577,12 +599,18 @@ full_xy(indices) = indices[1] isa Colon && indices[2] isa Colon          # the k
 hip_fill_applies(bcs, indices, zipper_expected) =
     full_xy(indices) && is_periodic(bcs.west) && is_periodic(bcs.east) && (!zipper_expected || bcs.north isa ZBC)
 
-# one C call per group of fields that share (element type, Nz, Hz): a tupled fill mixes 3-D and reduced fields
+# one C call per group of fields that share (element type, Nz, Hz): a tupled fill mixes 3-D and reduced fields.
+# The groups come back as a Vector of `key => field indices` in FIRST-APPEARANCE order, never as a Dict: on a latitude-band grid every
+# group issues one RCCL send / recv group, and group(k) of a rank pairs with group(k) of its neighbour (include/tripolar_hip.h) -- the
+# order must be a function of the argument list alone (the same on every rank), not of a hash table's iteration order.  The Python host
+# groups the same way (fields.py: insertion order).
 function fill_groups(fields, locs, indices, grid)
-    groups = Dict{Tuple{DataType, Int, Int}, Vector{Int}}()
+    groups = Pair{Tuple{DataType, Int, Int}, Vector{Int}}[]
     for (n, (c, loc)) in enumerate(zip(fields, locs))
         Nz, Hz = field_levels(c, loc, indices, grid)
-        push!(get!(groups, (eltype(parent(c)), Nz, Hz), Int[]), n)
+        key = (eltype(parent(c)), Nz, Hz)
+        at  = findfirst(g -> first(g) == key, groups)
+        at === nothing ? push!(groups, key => [n]) : push!(last(groups[at]), n)
     end
     return groups
 end

@@ -49,9 +49,11 @@ def _check_big_field(oracle, f, before_top, low_sum, xl, yl, sg):
     assert not bool((d[Hz:Hz + Nz, Hy:Ny - 1, :Hx] == 12345.0).any())   # sentinel gone from the x halos of interior rows and levels
 
 
-def test_config5_tupled_3d_fill(osg, oracle, gpu):
-    """fill_halo_regions!((u, v, T, S, c)) at 8640 x 4320 x 100, halo 4, Float64: one zipper launch + one periodic launch
-    over 162 GB of fields on one MI355X"""
+@pytest.mark.parametrize("HALO", [(4, 4, 4), (5, 5, 5)], ids=["halo4", "halo5"])
+def test_config5_tupled_3d_fill(osg, oracle, gpu, HALO):
+    """fill_halo_regions!((u, v, T, S, c)) at 8640 x 4320 x 100, Float64: ONE merged launch over 162 GB of fields on one MI355X --
+    at halo 4 and at halo (5, 5, 5), the halo the reference's own model examples run (examples/bickley_jet.jl:21,
+    examples/distributed_bickley_jet.jl:23; 165 GB)"""
     grid = osg.TripolarGrid(size=SIZE, halo=HALO)
     Nx, Ny, Nz = SIZE
     Hx, Hy, Hz = HALO
@@ -93,8 +95,9 @@ def test_config5_w_field_has_one_more_level(osg, oracle, gpu):
     assert np.array_equal(w.data.cpu().numpy(), h)
 
 
+@pytest.mark.parametrize("HALO", [(4, 4, 4), (5, 5, 5)], ids=["halo4", "halo5"])
 @pytest.mark.parametrize("mode", ["eager", "plan", "graph"])
-def test_config5_barotropic_substep_fills(osg, oracle, gpu, mode):
+def test_config5_barotropic_substep_fills(osg, oracle, gpu, mode, HALO):
     """eta, U, V of the split-explicit free surface at 8640 x 4320 with the extended north halo
     (Hy = substeps + 1 = 31 for the 30 sub-steps of examples/bickley_jet.jl:44): SUBSTEPS consecutive fills
     issued eagerly, through a reusable plan, and replayed from one captured HIP graph, whole arrays against the oracle."""

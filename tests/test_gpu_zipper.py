@@ -67,11 +67,16 @@ def test_reference_row_symmetry_testset(osg, gpu):
     assert torch.equal(urow[1:5], -urow[6:10].flip(0))                         # :68-72
 
 
-GEOMS = [((10, 10, 1), (4, 4, 4)), ((60, 30, 3), (4, 4, 4)), ((62, 31, 2), (3, 2, 1)),   # odd Hx -> scalar kernel
+GEOMS = [((10, 10, 1), (4, 4, 4)), ((60, 30, 3), (4, 4, 4)), ((62, 31, 2), (3, 2, 1)),   # odd Hx: chunks straddle the interior / x-halo boundary (GEN kernels)
          ((256, 40, 4), (4, 4, 2)), ((1000, 50, 2), (4, 4, 4)), ((130, 20, 3), (2, 5, 0)),
          ((6, 7, 1), (4, 4, 1)), ((4, 4, 2), (4, 4, 1)),
          ((64, 40, 1), (4, 13, 1)),      # extended north halo of the split-explicit free surface (test/runtests.jl:61-71): Hy > 8
-         ((3600, 24, 2), (4, 4, 4))]     # full 1/10 degree rows
+         ((3600, 24, 2), (4, 4, 4)),     # full 1/10 degree rows
+         # halo = (5, 5, 5): the reference's own model geometry (examples/bickley_jet.jl:21, examples/distributed_bickley_jet.jl:23)
+         ((10, 12, 1), (5, 5, 5)), ((60, 30, 3), (5, 5, 5)), ((3600, 24, 2), (5, 5, 5)), ((64, 44, 1), (5, 13, 1)),
+         # the other chunk geometries: Float32 8-B chunks (row pitch 2 mod 4), Nx = 2 mod 4 with an odd Hx, halo wider than one chunk + leftover
+         ((128, 20, 2), (5, 4, 1)), ((130, 20, 3), (3, 5, 0)), ((66, 20, 2), (6, 3, 2)), ((64, 16, 2), (7, 8, 1)), ((12, 12, 2), (5, 5, 1)),
+         ((10, 11, 2), (1, 1, 1))]
 
 
 class _Knob:
@@ -102,13 +107,14 @@ def fused_knob(osg, via_testlib):
     via_testlib.tpg_reload_config()
 
 
-@pytest.mark.parametrize("fused,merged", [("0", "0"), ("1", "0"), ("0", "1")], ids=["two-launch", "fused", "merged"])
+@pytest.mark.parametrize("fused,merged", [("0", "0"), ("1", "0"), ("0", "1"), ("2", "0")], ids=["two-launch", "fused", "merged", "fused-cells"])
 @pytest.mark.parametrize("size,halo", GEOMS, ids=[f"{s}-{h}" for s, h in GEOMS])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_fill_halo_regions_parity(osg, oracle, gpu, fused_knob, size, halo, dtype, fused, merged):
-    """zipper -> periodic x as two launches, as the single fused launch small fields take by default, and as the single
-    merged launch large fields take (geometries a single-launch form does not cover -- Nx < 2 Hx + 2, Ny < 2 Hy + 2,
-    unchunkable rows, Hy > 8 for the merged form -- fall back by themselves)"""
+    """zipper -> periodic x as two launches, as the single fused launch small fields take by default (chunk items; "fused-cells": its
+    one-thread-per-cell cross-check form), and as the single merged launch large fields take (geometries a single-launch form does not
+    cover -- Nx < 2 Hx + 2, Ny < 2 Hy + 2, Hy > 8 for the merged form -- fall back by themselves).  Every geometry has a chunked form:
+    plain 16-B chunks for halo (4, 4, 4)-like geometries, the element-aligned GEN form for an odd Hx, Float32 with Nx = 2 mod 4, ..."""
     fused_knob["TPG_FILL_FUSED"] = fused
     fused_knob["TPG_FILL_MERGED"] = merged
     tdt = torch.float64 if dtype == np.float64 else torch.float32
@@ -182,7 +188,8 @@ def test_more_fields_than_one_launch_holds(osg, oracle, gpu):
         assert np.array_equal(f.data.cpu().numpy(), h)
 
 
-def test_unaligned_base_pointer_takes_the_scalar_kernel(osg, oracle, gpu):
+def test_unaligned_base_pointer_takes_the_element_aligned_kernels(osg, oracle, gpu):
+    """a field that is only 8-B aligned: the GEN (element-aligned) form of the column kernel, and of the merged / fused fill"""
     size, halo = (32, 12, 2), (4, 4, 4)
     shape = (2 + 8, 12 + 8, 32 + 8)
     n = int(np.prod(shape))
@@ -196,6 +203,12 @@ def test_unaligned_base_pointer_takes_the_scalar_kernel(osg, oracle, gpu):
     torch.cuda.synchronize()
     oracle.zipper_fill(h, 1, 0, -1, size, halo)
     assert np.array_equal(view.cpu().numpy().reshape(shape), h)
+    h = np.random.default_rng(3).uniform(-1, 1, shape)
+    view.copy_(torch.from_numpy(h).flatten())
+    assert lib.tpg_fill_halo_regions(ptr, 1, (C.c_int8 * 1)(1), (C.c_int8 * 1)(0), (C.c_int32 * 1)(-1), *size, *halo, 1, 1, None) == 0
+    torch.cuda.synchronize()
+    oracle.fill_halo_regions(h, 1, 0, -1, size, halo)
+    assert np.array_equal(view.cpu().numpy().reshape(shape), h)
 
 
 def test_synthetic_fill_matches_host_twin(osg, gpu, tlib):
@@ -208,15 +221,17 @@ def test_synthetic_fill_matches_host_twin(osg, gpu, tlib):
         assert np.array_equal(d.cpu().numpy(), synthetic_field(0x5EED + 1, 12345.0, size, halo, dt))
 
 
-def test_config3_tenth_degree_75_levels(osg, oracle, gpu, tlib):
-    """BASELINE config 3: (3600,1800,75), halo 4, Float64, fields c(CC,+1) u(FC,-1) v(CF,-1) zeta(FF,+1),
+@pytest.mark.parametrize("h", [4, 5], ids=["halo4", "halo5"])
+def test_config3_tenth_degree_75_levels(osg, oracle, gpu, tlib, h):
+    """BASELINE config 3: (3600,1800,75), halo 4 -- and halo 5, the reference's model halo (examples/bickley_jet.jl:21): k_zipper_cols in its
+    GEN form --, Float64, fields c(CC,+1) u(FC,-1) v(CF,-1) zeta(FF,+1),
     splitmix64 interior / sentinel halos.  Full-size checks:
       * bit-exact parity of every row the fold can touch (rows Ny-Hy..Ny+Hy, all levels) against the
         oracle run on that slab as a short (Ny' = 2Hy+1) field -- the fold only looks Hy rows down;
       * everything below is untouched (checksum of the raw bits before/after);
       * x halos and z-halo levels of the north rows keep the sentinel (zipper only, no periodic pass).
     """
-    size, halo = (3600, 1800, 75), (4, 4, 4)
+    size, halo = (3600, 1800, 75), (h, h, h)
     (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
     lib = osg._lib.lib()
     specs = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]
@@ -247,10 +262,12 @@ def test_config3_tenth_degree_75_levels(osg, oracle, gpu, tlib):
         assert not bool((f[Hz:Hz + Nz, Ny + Hy:, Hx:Hx + Nx] == 12345.0).any())     # every halo cell of the fold written
 
 
+@pytest.mark.parametrize("h", [4, 5], ids=["halo4", "halo5"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_config3_merged_fill(osg, oracle, gpu, tlib, dtype):
+def test_config3_merged_fill(osg, oracle, gpu, tlib, dtype, h):
     """BASELINE config 3 through tpg_fill_halo_regions -- the ONE merged launch (k_fill_merged: zipper fold + periodic x) that
-    bench.py's step issues and `roofline` is quoted on -- at full size (3600, 1800, 75), halo 4, the four bench fields, against
+    bench.py's step issues and `roofline` is quoted on -- at full size (3600, 1800, 75), halo 4 (and halo 5, the reference's model
+    halo: the GEN form, Float32 in 8-B chunks), the four bench fields, against
     the oracle DIRECTLY (round 3 reached this kernel at this size only through the HIP serial fill):
       * every row the fold or a corner can touch (logical rows Ny-Hy .. Ny+Hy, ALL levels incl. the z halos, x halos included)
         is compared bit for bit with oracle.fill_halo_regions run on that slab as a short (Ny' = Hy+1) field: zipper on
@@ -258,7 +275,7 @@ def test_config3_merged_fill(osg, oracle, gpu, tlib, dtype):
         test/test_zipper_boundary_conditions.jl:42-45);
       * below the slab, on the device: interior bits untouched (checksum), x halos == the wrapped interior columns on every row
         and level, no sentinel left in them."""
-    size, halo = (3600, 1800, 75), (4, 4, 4)
+    size, halo = (3600, 1800, 75), (h, h, h)
     (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
     lib = osg._lib.lib()
     tdt, ft, ity = (torch.float64, 1, torch.int64) if dtype == np.float64 else (torch.float32, 0, torch.int32)
@@ -318,18 +335,21 @@ def test_randomised_geometries_against_the_oracle(osg, oracle, gpu):
 
 
 def test_fused_fill_randomised_against_the_oracle(osg, oracle, gpu, fused_knob):
-    """90 random geometries through tpg_fill_halo_regions with the fused kernel forced on, the merged kernel forced on, and
-    the automatic choice: whole padded array bit-identical to the oracle's zipper -> periodic x sequence"""
+    """120 random geometries through tpg_fill_halo_regions with the fused kernel forced on (chunk items), the merged kernel forced on,
+    the automatic choice, and the fused kernel in its one-thread-per-cell form: whole padded array bit-identical to the oracle's
+    zipper -> periodic x sequence"""
     lib = osg._lib.lib()
     rng = np.random.default_rng(4242)
-    for trial in range(90):
+    for trial in range(120):
         fused_knob["TPG_FILL_FUSED"] = "1"
         fused_knob["TPG_FILL_MERGED"] = "0"
-        if trial % 3 == 2:
+        if trial % 4 == 2:
             fused_knob.pop("TPG_FILL_FUSED")
-        if trial % 3 == 1:                                   # the merged large-field launch on the same random geometries
+        if trial % 4 == 1:                                   # the merged large-field launch on the same random geometries
             fused_knob["TPG_FILL_FUSED"] = "0"
             fused_knob["TPG_FILL_MERGED"] = "1"
+        if trial % 4 == 3:
+            fused_knob["TPG_FILL_FUSED"] = "2"
         Nx = int(rng.choice([4, 6, 10, 12, 14, 16, 30, 64, 66, 128, 130, 258]))
         Ny = int(rng.integers(2, 30))
         Nz = int(rng.integers(1, 4))
@@ -337,7 +357,7 @@ def test_fused_fill_randomised_against_the_oracle(osg, oracle, gpu, fused_knob):
         Hy = int(rng.integers(1, min(Ny, 9) + 1))
         Hz = int(rng.integers(0, 3))
         nf = int(rng.integers(1, 5))
-        dt, tdt, ft = ((np.float64, torch.float64, 1), (np.float32, torch.float32, 0))[trial % 2]
+        dt, tdt, ft = ((np.float64, torch.float64, 1), (np.float32, torch.float32, 0))[(trial // 4) % 2]
         specs = [(int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([1, -1, 2]))) for _ in range(nf)]
         hosts = [rng.uniform(-1, 1, (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)).astype(dt) for _ in specs]
         devs = [torch.from_numpy(h).to(gpu) for h in hosts]

@@ -317,10 +317,50 @@ def test_build_band_sets_the_tables_valid_flag_for_a_live_workspace():
     hdr = open(os.path.join(ROOT, "include", "tripolar_hip.h")).read()
     flag = int(re.search(r"#define TPG_BUILD_TABLES_VALID (\d+)", hdr).group(1))
     assert int(re.search(r"const TPG_BUILD_TABLES_VALID = Int32\((\d+)\)", src).group(1)) == flag
-    assert "const GRID_WORKSPACES = WeakKeyDict{Any, TableWorkspace}()" in src
+    assert "const GRID_WORKSPACES = WorkspaceOwner[]" in src and "keep_workspace!(arrays[1], ws)" in src
     assert "reuse ? TPG_BUILD_TABLES_VALID : Int32(0)" in src and "ws  = live_workspace(key, nbytes)" in src
     # the key holds exactly what the header says the tables depend on
     key = re.search(r"table_key\(arch, FT, Nλ, Nφ, Hφ, south, npl, radius\) = \((.*)\)", src).group(1)
     for part in ("serial_arch(arch)", "FT", "Int(Nλ)", "Int(Nφ)", "Int(Hφ)", "Float64(south)", "Float64(npl)", "Float64(radius)"):
         assert part in key
     assert "first_pole" not in key and "jstart" not in key and "Hλ" not in key
+
+
+def test_no_table_is_keyed_by_a_device_array():
+    """ADVICE r5 (high): a Dict / WeakKeyDict keyed by a device array hashes and compares the array's ELEMENTS (Base.hash(::AbstractArray)
+    indexes them); HIPArray refuses scalar indexing, so `GRID_WORKSPACES[arrays[1]] = ws` threw at the end of every build.  The table that
+    ties a workspace to its grid is a Vector of (WeakRef(owner), workspace) entries matched with === and pruned under STATE_LOCK; the only
+    remaining dictionaries are identity-keyed (IdDict on the architecture value, task_local_storage())."""
+    code = _code(JL)
+    assert "WeakKeyDict" not in code
+    assert re.findall(r"(?<![A-Za-z])Dict\{", code) == [], "a hashed Dict in the glue: key it by identity (IdDict) or use a Vector"
+    assert re.search(r"struct WorkspaceOwner\s+owner::WeakRef", code) and "e.owner.value === a && return e.workspace" in code
+    assert "filter!(e -> e.owner.value !== nothing, table)" in code
+    # nothing is indexed or looked up BY an array: no `[arrays[1]]` / `get(..., parent(...)` on a table
+    assert "[arrays[1]]" not in code and not re.search(r"get!?\([A-Z_]+, parent\(", code)
+    assert "const SEAM_COMMS = IdDict{Any, SeamComm}()" in code
+
+
+def test_group_order_is_a_function_of_the_argument_list():
+    """group(k) of a rank's seam exchange pairs with group(k) of its neighbour (include/tripolar_hip.h), so the order
+    in which a tupled fill's geometry groups issue their RCCL groups must be the same on every rank.  fill_groups returns a Vector of
+    `key => indices` in first-appearance order (as fields.py's insertion-ordered dict does); no function that issues tpg_halo_exchange_y* /
+    tpg_fill_halo_regions_distributed* iterates a Dict."""
+    src = open(JL).read()
+    code = _code(JL)
+    body = code[code.index("function fill_groups("):code.index("as_tuple(x::Tuple)")]
+    assert "groups = Pair{Tuple{DataType, Int, Int}, Vector{Int}}[]" in body and "Dict" not in body
+    assert "findfirst(g -> first(g) == key, groups)" in body and "push!(groups, key => [n])" in body
+    # every function whose body reaches an exchange entry point: iterates fill_groups(...) (a Vector) and no Dict / keys() / values() / pairs()
+    starts = [m.start() for m in re.finditer(r"(?m)^function \w+!?\(", code)] + [len(code)]
+    issuing = []
+    for a, b in zip(starts, starts[1:]):
+        fn = code[a:b]
+        if re.search(r":tpg_(halo_exchange_y|fill_halo_regions_distributed)", fn):
+            issuing.append(fn)
+            assert "in fill_groups(" in fn, fn[:80]
+            for banned in ("Dict", "keys(", "values(", "pairs(", "Set("):
+                assert banned not in fn, (banned, fn[:80])
+    assert len(issuing) == 2                                             # hip_fill! and halo_exchange_y!
+    fpy = open(os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "fields.py")).read()
+    assert "groups.setdefault(key, []).append(f)" in fpy and "return groups.values()" in fpy    # insertion order on the Python side
