@@ -10,6 +10,7 @@
 // Elementwise, HBM-bound (24 B and 2 x 3 x s B per cell); same deterministic Float64 functions as the metric
 // kernels (tpg_math.hpp), so results are bit-identical to the CPU restatement's (tests/).
 #include "tpg_common.hpp"
+#include <type_traits>
 #include "tpg_math.hpp"
 
 using namespace tpgm;
@@ -113,17 +114,21 @@ __global__ __launch_bounds__(256) void k_convert_frame(const T* __restrict__ phi
 }
 
 // 16-byte form: a thread owns W adjacent columns (2 doubles / 4 floats) of ZCH consecutive levels -- W sets of direction
-// cosines, 16-B streaming loads and stores (Nx and Hx multiples of W, 16-B aligned arrays; otherwise the scalar kernel).
+// cosines, 16-B streaming loads and stores (Nx a multiple of W; otherwise the scalar kernel).  LOOSE = true: the same chunks accessed
+// element-aligned, for an Hx that is not a multiple of W -- the reference's model halo (5, 5, 5), examples/bickley_jet.jl:21 -- or
+// 16-B-misaligned arrays (the halo-fill kernels' GEN form does the same: csrc/tpg_zipper_kernels.hpp).
 // Threads are numbered over (chunk, row) jointly: a row of 3600 columns is 1800 chunks = 7.03 blocks of 256, and a grid with one block
 // row per grid row would leave every eighth block with 8 live lanes (round 5, tools/frame_ab.py: -3 .. -5 % with the flat numbering;
 // more loads in flight, plain loads, 8 / 32 / all levels per thread: all within +-2 %).
-template <typename T, int W>
+template <typename T, int W, bool LOOSE>
 __global__ __launch_bounds__(256) void k_convert_frame_vec(const T* __restrict__ phi_cf, const T* __restrict__ phi_fc,
                                                            const T* __restrict__ dy_cc, const T* __restrict__ dx_cc,
                                                            const T* __restrict__ u, const T* __restrict__ v,
                                                            T* __restrict__ uo, T* __restrict__ vo, FrameArgs a)
 {
-    typedef T vec_t __attribute__((ext_vector_type(W)));
+    typedef T aligned_t __attribute__((ext_vector_type(W)));
+    typedef T loose_t __attribute__((ext_vector_type(W), aligned(sizeof(T))));
+    typedef typename std::conditional<LOOSE, loose_t, aligned_t>::type vec_t;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int per_row = a.Nx / W;
     if (t >= (long long)per_row * a.Ny) return;
@@ -206,18 +211,17 @@ int tpg_convert_frame(const void* phi_cf, const void* phi_fc, const void* dy_cc,
     FrameArgs a{ Nx, Ny, Nz, Hx, Hy, Hz, g.sx, g.plane, to_native ? 1 : 0 };
     hipStream_t s = tpg::as_stream(stream);
     const int W = ft == TPG_F64 ? 2 : 4;
-    bool vec = (Nx % W == 0) && (Hx % W == 0);
-    for (const void* q : { u, v, (const void*)u_out, (const void*)v_out }) vec = vec && ((uintptr_t)q % 16) == 0;
-    if (vec) {
+    if (Nx % W == 0) {
+        bool aligned = Hx % W == 0;
+        for (const void* q : { u, v, (const void*)u_out, (const void*)v_out }) aligned = aligned && ((uintptr_t)q % 16) == 0;
         dim3 grid((unsigned)(((long long)(Nx / W) * Ny + 255) / 256), (Nz + ZCH - 1) / ZCH);      // (chunk, row) jointly; level groups on y
-        if (ft == TPG_F64)
-            hipLaunchKernelGGL((k_convert_frame_vec<double, 2>), grid, dim3(256), 0, s, static_cast<const double*>(phi_cf), static_cast<const double*>(phi_fc),
-                               static_cast<const double*>(dy_cc), static_cast<const double*>(dx_cc), static_cast<const double*>(u),
-                               static_cast<const double*>(v), static_cast<double*>(u_out), static_cast<double*>(v_out), a);
-        else
-            hipLaunchKernelGGL((k_convert_frame_vec<float, 4>), grid, dim3(256), 0, s, static_cast<const float*>(phi_cf), static_cast<const float*>(phi_fc),
-                               static_cast<const float*>(dy_cc), static_cast<const float*>(dx_cc), static_cast<const float*>(u),
-                               static_cast<const float*>(v), static_cast<float*>(u_out), static_cast<float*>(v_out), a);
+#define TPG_FRAME_LAUNCH(T, W_, LOOSE_)                                                                                                    \
+        hipLaunchKernelGGL((k_convert_frame_vec<T, W_, LOOSE_>), grid, dim3(256), 0, s, static_cast<const T*>(phi_cf), static_cast<const T*>(phi_fc), \
+                           static_cast<const T*>(dy_cc), static_cast<const T*>(dx_cc), static_cast<const T*>(u), static_cast<const T*>(v),   \
+                           static_cast<T*>(u_out), static_cast<T*>(v_out), a)
+        if (ft == TPG_F64) { if (aligned) TPG_FRAME_LAUNCH(double, 2, false); else TPG_FRAME_LAUNCH(double, 2, true); }
+        else               { if (aligned) TPG_FRAME_LAUNCH(float, 4, false);  else TPG_FRAME_LAUNCH(float, 4, true); }
+#undef TPG_FRAME_LAUNCH
         return tpg::launch_status("k_convert_frame_vec");
     }
     dim3 grid((Nx + 255) / 256, Ny, (Nz + ZCH - 1) / ZCH);

@@ -75,6 +75,16 @@ def test_bench_prints_one_contract_line(gpu):
     fs = d["fill_step"]
     assert "skipped" in fs or (fs["fill3d_us"] > 0 and fs["substep_fills_us"] > 0 and fs["substeps"] == 30
                                and abs(fs["total_us"] - fs["fill3d_us"] - fs["substep_fills_us"]) < 1e-6 and fs["fields_GB"] > 160)
+    # the same fills at the reference's own model halo (5, 5, 5) (examples/bickley_jet.jl:21), halo 4 by the same method beside them:
+    # ONE launch per fill at the odd Hx too (the first kernel's duration is the whole call's, minus the event bracket's overhead)
+    h5 = d["fill_step_halo5"]
+    a5, a4 = h5["headline_halo5"], h5["headline_halo4_same_method"]
+    assert a5["halo"] == [5, 5, 5] and a4["halo"] == [4, 4, 4] and a4["fill_algorithmic_bytes"] == zb + pb
+    assert a5["fill_algorithmic_bytes"] == 90720000 + 4 * 1810 * 85 * 160 and a5["fold_algorithmic_bytes"] == 90720000
+    assert 0 < a5["fill_first_kernel_ms"] <= a5["fill_ms"] < a5["fill_first_kernel_ms"] + 0.03          # one launch, not two
+    assert 0.7 < h5["headline_time_per_byte_halo5_over_halo4"] < 1.25 and 0.7 < h5["headline_fold_time_per_byte_halo5_over_halo4"] < 1.25
+    if "skipped" not in h5.get("config5_halo5", {"skipped": 1}):
+        assert h5["config5_halo5"]["fields_GB"] > 164 and 0.7 < h5["config5_time_per_byte_halo5_over_halo4"] < 1.25
 
 
 def _two_rank_bench(extra, launcher="self", ranks=2):
@@ -177,26 +187,51 @@ def test_bench_production_branch_between_real_processes_over_the_test_double(gpu
     assert "monolithic" in d["ms_per_step_by_form"] and d["ms_per_step"] == d["ms_per_step_by_form"][d["exchange_form"]]
 
 
-def test_bench_a_stalled_pipelined_probe_costs_the_probe_not_the_run(gpu):
+def test_bench_a_stalled_pipelined_probe_costs_the_probe_not_the_line(gpu):
     """The pipelined exchange forms have never met a second RCCL rank.  They are probed only AFTER the run has been made with the monolithic
     form and rank 0 holds the line; here rank 1 of a two-rank run through the production branch (test double of librccl) never enters the
     probe (TPG_BENCH_TEST_STALL_PIPELINED): the soft watchdog must print ONE diagnostic per rank on stderr, rank 0 must still print the
-    contract line -- the monolithic form's, `pipelined_probe.status == "stalled"`, no pipelined figures -- and the job must exit 0."""
+    contract line -- the monolithic form's, `pipelined_probe.status == "stalled"`, no pipelined figures -- and the job must leave with
+    status 9 (a hang inside a product entry point is not a successful run; the line is out, the status says so)."""
     env = dict(os.environ, TPG_BENCH_REHEARSE="shim", MASTER_ADDR="127.0.0.1", TPG_BENCH_TEST_STALL_PIPELINED="1", TPG_SHIM_DEADLINE_S="120")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TPG_RCCL_LIBRARY"):
         env.pop(k, None)
     t0 = time.time()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--preroll", "8", "--deadline", "10"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert p.returncode == 0 and time.time() - t0 < 200, (p.returncode, p.stderr[-3000:])
+    assert p.returncode == 9 and time.time() - t0 < 200, (p.returncode, p.stderr[-3000:])
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith('{"metric"'), p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["pipelined_probe"]["status"] == "stalled" and "pipelined probe (pipelined_1)" in d["pipelined_probe"]["phase"]
+    assert d["pipelined_probe"]["exit_status"] == 9
     assert d["exchange_form"] == "monolithic" and d["exchange_ms_monolithic"] > 0 and d["exchange_ms_pipelined_1"] is None
     assert d["ms_per_step_by_form"] == {"monolithic": d["ms_per_step"]} and all(r["seams_bit_exact"] for r in d["per_rank"])
     diag = [json.loads(l[l.index("{"):]) for l in p.stderr.splitlines() if "pipelined_probe_stalled" in l]
     assert {x["rank"] for x in diag} == {0, 1}
+
+
+def test_bench_wrong_seams_from_a_pipelined_form_fail_the_job_after_the_line(gpu):
+    """a pipelined form that delivers halos which are not bit-exact (here: one received cell altered on rank 0 right
+    before the probe's seam verification, TPG_BENCH_TEST_CORRUPT_PIPELINED_SEAM) must not be recorded as a successful run.  The monolithic
+    line is still printed -- with `pipelined_probe.status == "seam_mismatch"` and no figures for the failed form --, a `seam_mismatch`
+    diagnostic names side and field on stderr, and EVERY rank leaves with status 9."""
+    env = dict(os.environ, TPG_BENCH_REHEARSE="shim", MASTER_ADDR="127.0.0.1", TPG_BENCH_TEST_CORRUPT_PIPELINED_SEAM="0", TPG_SHIM_DEADLINE_S="60")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TPG_RCCL_LIBRARY"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--preroll", "8"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 9, (p.returncode, p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), p.stdout[-2000:]
+    d = json.loads(lines[0])
+    pp = d["pipelined_probe"]
+    assert pp["status"] == "seam_mismatch" and pp["exit_status"] == 9 and set(pp["forms"].values()) == {"seam_mismatch"}
+    assert d["exchange_form"] == "monolithic" and d["exchange_ms_pipelined_1"] is None and d["exchange_ms_pipelined_2"] is None
+    assert all(r["seams_bit_exact"] for r in d["per_rank"])                     # the monolithic run itself was verified and stands
+    diag = [json.loads(l[l.index("{"):]) for l in p.stderr.splitlines() if '"seam_mismatch"' in l and l.lstrip().startswith("{")]
+    assert diag and all(x["rank"] == 0 and x["bit_exact"] is False and x["exit_status"] == 9 for x in diag)
+    assert {x["form"] for x in diag} == {"pipelined_1", "pipelined_2"}
 
 
 def test_bench_stalled_teardown_is_reported(gpu):

@@ -40,7 +40,7 @@ def test_nonorthogonality_parity(osg, oracle, gpu, size, kw, dtype):
         assert float(masked.max()) < 2.0 and float(masked.min()) > -2.0
 
 
-@pytest.mark.parametrize("nz,halo", [(3, (4, 4, 2)), (21, (4, 4, 4)), (5, (3, 2, 1))], ids=["16B", "16B-21-levels", "scalar"])
+@pytest.mark.parametrize("nz,halo", [(3, (4, 4, 2)), (21, (4, 4, 4)), (5, (3, 2, 1)), (20, (5, 5, 5))], ids=["16B", "16B-21-levels", "element-aligned", "model-halo-5"])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 def test_frame_conversion_parity(osg, oracle, gpu, dtype, nz, halo):
     size = (180, 90, nz)                                                  # the example's grid (:58)

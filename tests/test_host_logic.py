@@ -141,13 +141,14 @@ def test_bench_watchdog_fires_with_one_json_line():
     assert d["event"] == "bench_deadline_expired" and d["rank"] == 2 and d["peers"] == {"south": 1, "north": 3}
     assert d["phase"] == "first seam exchange: device" and d["deadline_s"] == 0.3
     # SOFT mode (the pipelined probe of an N > 1 run): on expiry the callback runs -- it prints what the run already holds -- and the
-    # process leaves with status 0 instead of 3, also from under a blocked main thread
+    # process leaves with status 9 (bench_chain.PROBE_FAILED: the line is out, but a product entry point did not come back) instead of 3,
+    # also from under a blocked main thread
     code3 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
              "d = bench.Watchdog(0.3, {'rank': 0})\n"
              "d.soft = lambda dog: print('LINE-IN-HAND after', dog.phase, flush=True)\n"
              "d.arm('pipelined probe (pipelined_1): first exchange'); time.sleep(20); print('not reached')\n" % root)
     p3 = subprocess.run([sys.executable, "-c", code3], capture_output=True, text=True, timeout=60)
-    assert p3.returncode == 0 and "not reached" not in p3.stdout and "LINE-IN-HAND after pipelined probe (pipelined_1): first exchange" in p3.stdout
+    assert p3.returncode == 9 and "not reached" not in p3.stdout and "LINE-IN-HAND after pipelined probe (pipelined_1): first exchange" in p3.stdout
     assert "bench_deadline_expired" not in p3.stderr
     # a disarmed watchdog does nothing
     code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
@@ -226,7 +227,7 @@ def test_traffic_json_is_keyed_per_kernel_source():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
-    import bench
+    import bench_common as bench                                            # load_traffic / sources_sha16 live there (bench.py re-exports them)
     tj = json.load(open(os.path.join(root, "profiles", "traffic.json")))
     assert "kernel_source_sha16" not in tj                                   # the single global key is gone
     ks = tj["kernels"]

@@ -9,6 +9,10 @@ A `step` whose kernels follow each other within 5 us is a TIMED step (the instru
 its phases, ~10 us each); only those enter the `timed_step` rows, which are the figures to compare with `roofline`.  Marker-free
 steps that come AFTER the fold pass are the K cold-onset steps of round 5 (`ms_per_step_cold_onset`: started right after 100 passes
 over 1 GiB): they get their own `cold_onset_step` rows.
+Beside those step sequences every launch of a HALO-FILL kernel gets a row of its own kind: the launches are grouped by kernel, template
+arguments (element type, chunk width, Hy, GEN), number of fields (Grid_Size_Y) and grid width -- so the 8- and 16-field batched folds
+behind `roofline_fold_batched` and the halo-(5, 5, 5) launches behind `fill_step_halo5` are rows of their own (`fill_launch` rows; their
+medians are the figures to compare with bench.py's medians, both being cold launches).
 usage: tools/trace_summary.py <bench_kernel_trace.csv> [out.csv]"""
 import csv
 import re
@@ -24,6 +28,12 @@ def short(name):
     return m.group(1) if m else name[:40]
 
 
+def is_copy_probe(kernel_name):
+    """k_zipper_cols<T, W, HY, COPY, GEN>: the same-shape copy probe of the test library has COPY = true"""
+    args = kernel_name.split("k_zipper_cols<")[1].split(">")[0].replace(" ", "").split(",")
+    return len(args) > 3 and args[3] == "true"
+
+
 def main():
     rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
     names = [short(r["Kernel_Name"]) for r in rows]
@@ -34,7 +44,7 @@ def main():
            "cold_onset_step": {k: [] for k in STEP}}
     i, seen_fold = 0, False
     while i < len(rows):
-        if names[i:i + len(FOLD)] == FOLD and "true>" not in rows[i + 3]["Kernel_Name"].split("k_zipper_cols")[1][:24]:
+        if names[i:i + len(FOLD)] == FOLD and not is_copy_probe(rows[i + 3]["Kernel_Name"]):
             for k, d in zip(FOLD, dur[i:i + len(FOLD)]):
                 acc["fold_pass"][k].append(d)
             i += len(FOLD)
@@ -47,12 +57,24 @@ def main():
             i += len(STEP)
         else:
             i += 1
+    # every halo-fill launch by (kernel<template>, fields, grid width)
+    FILL = ("k_zipper_cols", "k_fill_merged", "k_fill_fused_vec", "k_fill_fused", "k_zipper_scalar", "k_zipper_vec", "k_periodic_x")
+    fills = {}
+    for r, d in zip(rows, dur):
+        m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", r["Kernel_Name"])
+        if not m or not m.group(1).startswith(FILL):
+            continue
+        key = (m.group(1) + (m.group(2) or "").replace(" ", ""), int(r["Grid_Size_Y"]), int(r["Grid_Size_X"]))
+        fills.setdefault(key, []).append(d)
     out = [("sequence", "kernel", "launches", "avg_us", "median_us", "min_us", "max_us")]
     for kind, order in (("timed_step", STEP), ("instrumented_step", STEP), ("fold_pass", FOLD), ("cold_onset_step", STEP)):
         for k in order:
             d = acc[kind][k]
             if d:
                 out.append((kind, k, len(d), round(statistics.mean(d), 3), round(statistics.median(d), 3), round(min(d), 3), round(max(d), 3)))
+    for (name, ny, nx), d in sorted(fills.items()):
+        out.append(("fill_launch", f"{name} fields={ny} grid_x={nx}", len(d), round(statistics.mean(d), 3), round(statistics.median(d), 3),
+                    round(min(d), 3), round(max(d), 3)))
     w = csv.writer(open(sys.argv[2], "w", newline="") if len(sys.argv) > 2 else sys.stdout)
     w.writerows(out)
 
