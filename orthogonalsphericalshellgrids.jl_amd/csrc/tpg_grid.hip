@@ -27,6 +27,12 @@
 //                    tile form's 499 us at 1/10 degree; removed, history in DESIGN.md 4.)
 //   K2 halos       : compact pass over halo cells only (x-halo columns, north fold rows, zero
 //                    south rows of the coordinates, row-Ny substitution of the y-Center metrics).
+//                    Since round 6 the tile kernel PUSHES these cells itself (HaloPush below: the thread that
+//                    produces a value also stores its periodic, fold and substitution images, the south
+//                    tiles' apron waves the zero / continuation rows), so the default build is K0 + K1;
+//                    K2 / K3 remain for the thread-per-cell form, for grids too short or narrow for the
+//                    images to be distinct cells (Ny <= 2 Hy + 2, Nx < 2 Hx + 2), and as the cross-check
+//                    (TPG_CELLS_VARIANT=2: tile kernel + K2, the round-5 default).
 //   K3 south       : lat-lon continuation rows j = 1-Hy..1 of the 12 metrics (south rank only).
 //
 // No inter-rank communication: seam halo rows are the neighbour's interior rows of the same
@@ -280,6 +286,95 @@ __device__ __forceinline__ void put32(const OutPtrs& o, int q, unsigned boff, do
     asm volatile("" : "+v"(boff));
     T* p = reinterpret_cast<T*>(static_cast<char*>(o.p[q]) + boff);
     if (NT) __builtin_nontemporal_store((T)v, p); else *p = (T)v;
+}
+
+// ---- halo images pushed by the producer (round 6) ------------------------------------------------------------------------
+// K2 (k_halos) copies every halo cell of the 20 arrays from the interior cell that defines it: a second launch (6.8 us + a kernel
+// boundary: 3 % of the 1/10 degree build, 7-9 % of a 1/4 degree build or of a 225-row band of BASELINE config 4).  The same cells can
+// be written by the thread that PRODUCES the value, because every one of K2's index maps is a bijection from sources to destinations:
+//   periodic x        the x-halo columns i = 1-Hx .. 0 and Nx+1 .. Nx+Hx are simply CELLS of the tile grid (it spans 1-Hx .. Nx+Hx): the
+//                     wrapped column feeds the same arithmetic, so the same bits come out, and the stores stay whole coalesced rows.
+//                     (Pushing them as images from the first / last interior columns cost what K2 saved: + 3.7 us of partial-wave
+//                     stores in the two edge tile columns; profiles/r06/build_push_ab.txt)                          [src/tripolar_grid.jl:149-150]
+//   north fold, +1    (i, j) with dj = Ny - j (+1 for y-Face arrays) in 1 .. rows present: at (i*, Ny + dj), i* = Nx - i + 1 (x-Center) or
+//                     Nx - i + 2 (x-Face; i = 1 -> 1), and at the periodic images of THAT cell (the corners)       [:147; zipper_boundary_condition.jl:70-138]
+//   row-Ny substitution of the y-Center METRICS: (i, Ny) with partner i' = Nx - i + 1 / Nx - i + 2 in Nx/2+1 .. Nx also lands at (i', Ny) and
+//                     its west image; the thread that owns (i', Ny) does not store there                            [zipper_boundary_condition.jl:102,135]
+//                     (the coordinates were evaluated through the substitution already: coord())
+//   south             rows j < 1 of the coordinates are 0.0 (src/tripolar_grid.jl:148), rows j <= 1 of the metrics the lat-lon
+//                     continuation (:277-300, continue_south!): constants per row, written for their 62 columns (+ x-halo images) by the
+//                     apron wave of the southernmost tiles; the cells of row 1 do not store their metrics.
+// Only EDGE tiles do any of this (block-uniform test): the tile rows that reach row Ny - Hy and the southernmost tile row.  Valid where source and images are distinct cells -- Ny > 2 Hy + 2 and Nx >= 2 Hx + 2; other grids keep K2 / K3.
+struct HaloPush {
+    int on;       // 1: the tile kernel writes every halo cell itself
+    int jn_hi;    // last north halo row present in the band: min(jend + Hy, Ny + Hy); Ny = none
+    int south;    // 1: the band holds rows j <= 1 whose metrics are the lat-lon continuation (south_in_band)
+    int j_lo;     // first row of the band's parent: jstart - Hy
+};
+
+// value v of array q (location xl, yl; metric or coordinate; all four compile-time constants at the call sites) produced at the interior cell
+// (i, j), whose own cell is at byte offset boff: the own cell and every image of it, as saddr stores at offsets derived from boff.  The images
+// are PLAIN stores whatever NT says: they are 32-40 B pieces of a line (a few lanes of the wave), which a streaming store would send past
+// the L2 as partial-line writes.  Inlined:
+// a few integer operations and predicated stores per site, in edge tiles only (a first version behind a noinline call, with g / o copied to
+// scratch for it, ran the 1/4 degree build at 344 us instead of 102: profiles/r06/build_push_ab.txt).
+template <typename T, bool NT>
+__device__ __forceinline__ void emit_edge(const GridK& g, const HaloPush& hp, const OutPtrs& o, int q, int xl, int yl, bool metric, int i, int j,
+                                          unsigned boff, double v)
+{
+    constexpr int sz = (int)sizeof(T);
+    const int Nx = g.Nx, Ny = g.Ny, Hx = g.Hx;
+    const int iw = i < 1 ? i + Nx : (i > Nx ? i - Nx : i);                   // an x-halo column is a cell of its own: same value as column iw
+    const int ipart = Nx - iw + 1 + xl;                                      // un-wrapped fold partner (x-Face iw = 1: Nx + 1)
+    const unsigned pw = (unsigned)(Nx * sz);                                 // byte distance of a periodic image
+    const bool rowNyC = metric && yl == TPG_CENTER && j == Ny;
+    const bool dest = rowNyC && iw > Nx / 2 && ipart != iw;                   // a substitution destination (or its west image): the partner writes it
+    const bool south_row = metric && hp.south && j <= 1;                      // a continuation row: the south tiles' apron waves write it
+    if (!dest && !south_row) put32<T, NT>(o, q, boff, v);
+    if (i < 1 || i > Nx) return;                                              // images are pushed from the interior instance of a column only
+    if (rowNyC && ipart > Nx / 2 && ipart <= Nx && ipart != i) {
+        const unsigned b2 = boff + (unsigned)((ipart - i) * sz);
+        put32<T, false>(o, q, b2, v);
+        if (ipart > Nx - Hx) put32<T, false>(o, q, b2 - pw, v);
+    }
+    const int dj = Ny - j + yl;                                              // fold image row Ny + dj: (Ny + dj) - j = 2 dj - yl rows up
+    if (dj >= 1 && Ny + dj <= hp.jn_hi) {
+        const int iwd = ipart > Nx ? ipart - Nx : ipart;
+        const unsigned b3 = boff + (unsigned)(((iwd - i) + g.sx * (2 * dj - yl)) * sz);
+        put32<T, false>(o, q, b3, v);
+        if (iwd <= Hx) put32<T, false>(o, q, b3 + pw, v);
+        if (iwd > Nx - Hx) put32<T, false>(o, q, b3 - pw, v);
+    }
+}
+
+// the south rows of column i (interior or x halo): zeros below row 1 of the 8 coordinate arrays, the continuation rows j <= 1 of the 12 metrics;
+// boff1 = byte offset of (i, 1)
+template <typename T, bool NT>
+__device__ __forceinline__ void emit_south(const GridK& g, const HaloPush& hp, const OutPtrs& o, unsigned boff1)
+{
+    constexpr int sz = (int)sizeof(T);
+    const int n = g.Hy + 1;
+    const unsigned rw = (unsigned)(g.sx * sz);
+#pragma unroll 1
+    for (int j = hp.j_lo; j <= 1; ++j) {
+        const int rt = j - (1 - g.Hy);
+        const unsigned b = boff1 - rw * (unsigned)(1 - j);
+        double tv[5];                                                       // the row's five continuation values, loaded before the first store
+#pragma unroll
+        for (int c = 0; c < 5; ++c) tv[c] = g.ts[c * n + rt];
+#pragma unroll
+        for (int q = 0; q < TPG_NUM_ARRAYS; ++q) {
+            double v = 0.0;
+            if (q >= TPG_DX_CC) {
+                const int yl = (q >= TPG_DY_CC && q <= TPG_DY_FF) ? (q & 1) : ((q & 3) >> 1);          // array_loc(): dy is cc, cf, fc, ff
+                const int col = (q >= TPG_DY_CC && q <= TPG_DY_FF) ? 4 : ((q >= TPG_AZ_CC ? 2 : 0) + (yl == TPG_FACE ? 1 : 0));
+                v = tv[col];
+            } else if (j >= 1) {
+                continue;                                                   // row 1 of the coordinates is the cells'
+            }
+            put32<T, NT>(o, q, b, v);
+        }
+    }
 }
 
 // ---- K1: interior cells ------------------------------------------------------------------------
@@ -575,7 +670,7 @@ __device__ __forceinline__ void hav_batch(const Nb (&X)[N], const Nb (&Y)[N], do
 }
 
 template <typename T, bool NT, int R>
-__global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, int tiles_x)
+__global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, int tiles_x, HaloPush hp)
 {
     __shared__ __attribute__((aligned(16))) double atabs[R][TPG_ATAN_TABLE_DOUBLES];
     __shared__ TileLds<R> lds;
@@ -591,17 +686,32 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
     // Tile rows are dispatched in blockIdx.y order: NORTH to SOUTH, so that the one slow row of a launch -- row Ny, whose wave takes the
     // general (scalar) path through coord(): +2.2 us of block latency -- starts first instead of ending the launch.  Worth ~0.3 % at
     // 1/10 degree (in-process A/B, round 4: 505.7 -> 504.2 us per build, i.e. inside the noise); kept because it costs nothing.
-    const int ty = (int)gridDim.y - 1 - (int)blockIdx.y;
+    // With the halo push (hp.on) the EDGE tile rows carry extra stores and must not be the last blocks of the launch, where their extra time
+    // would add to the kernel's: the southernmost tile row is dispatched right after the northernmost, the others follow north to south.
+    int ty = (int)gridDim.y - 1 - (int)blockIdx.y;
     const int tx = blockIdx.x;
+    if (hp.on) {
+        const int ny_t = (int)gridDim.y, by = (int)blockIdx.y;
+        ty = by == 0 ? ny_t - 1 : (by == 1 ? 0 : ny_t - by);
+    }
     const int s0 = g.jm_lo - 1 + ty * (R - 1);
     const int s = s0 + p;                                                    // this wave's step
-    int i = tx * 62 + lane;
-    const bool col_emit = lane >= 1 && lane <= 62 && i <= g.Nx;
-    if (i > g.Nx + 1) i = g.Nx + 1;
+    // columns: 1 .. Nx -- or, with the halo push, 1-Hx .. Nx+Hx: the x-halo columns are cells of the tile grid (wrapped below)
+    const int i_hi = hp.on ? g.Nx + g.Hx : g.Nx;
+    int i = tx * 62 + lane - (hp.on ? g.Hx : 0);
+    const bool col_emit = lane >= 1 && lane <= 62 && i <= i_hi;
+    if (i > i_hi + 1) i = i_hi + 1;
     const double Rad = g.R;
     const bool active_row = s <= g.jm_hi;                                    // rows past the band: idle waves
     const unsigned col = (unsigned)(i + g.Hx - 1);
     auto rowoff = [&](int j) -> unsigned { return (col + (unsigned)g.sx * (unsigned)(j - g.jstart + g.Hy)) * (unsigned)sizeof(T); };   // bytes
+    // EDGE tiles also store the halo images of what they produce (HaloPush above); block-uniform, so every other tile runs the code it ran
+    // before.  emit(): array q at location (xl, yl), row j -- the plain store, or (edge tiles) own cell + images.
+    const bool edge = hp.on && (s0 + R >= g.Ny - g.Hy || (hp.south && ty == 0));
+    auto emit = [&](int q, int xl, int yl, bool metric, int j, unsigned boff, double v) {
+        if (edge) emit_edge<T, NT>(g, hp, o, q, xl, yl, metric, i, j, boff, v);
+        else put32<T, NT>(o, q, boff, v);
+    };
 
     // ---- phase 1: one point set per thread
     Step4 q;
@@ -622,13 +732,13 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         if (col_emit) {
             if (p >= 1 && s >= g.jm_lo) {
                 unsigned off = rowoff(s);
-                put32<T, NT>(o, TPG_LAMBDA_FC, off, q.lam[0]); put32<T, NT>(o, TPG_PHI_FC, off, q.phi[0]);
-                put32<T, NT>(o, TPG_LAMBDA_CC, off, q.lam[1]); put32<T, NT>(o, TPG_PHI_CC, off, q.phi[1]);
+                emit(TPG_LAMBDA_FC, 1, 0, false, s, off, q.lam[0]); emit(TPG_PHI_FC, 1, 0, false, s, off, q.phi[0]);
+                emit(TPG_LAMBDA_CC, 0, 0, false, s, off, q.lam[1]); emit(TPG_PHI_CC, 0, 0, false, s, off, q.phi[1]);
             }
             if ((p >= 1 || ty == 0) && s + 1 >= g.jm_lo && s + 1 <= g.jm_hi) {
                 unsigned off1 = rowoff(s + 1);
-                put32<T, NT>(o, TPG_LAMBDA_FF, off1, q.lam[2]); put32<T, NT>(o, TPG_PHI_FF, off1, q.phi[2]);
-                put32<T, NT>(o, TPG_LAMBDA_CF, off1, q.lam[3]); put32<T, NT>(o, TPG_PHI_CF, off1, q.phi[3]);
+                emit(TPG_LAMBDA_FF, 1, 1, false, s + 1, off1, q.lam[2]); emit(TPG_PHI_FF, 1, 1, false, s + 1, off1, q.phi[2]);
+                emit(TPG_LAMBDA_CF, 0, 1, false, s + 1, off1, q.lam[3]); emit(TPG_PHI_CF, 0, 1, false, s + 1, off1, q.phi[3]);
             }
         }
         double (*L)[R][64] = lds.v;
@@ -644,6 +754,7 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         // The apron wave has no cell row of its own: instead of idling through phase 2 it computes one of the
         // eight haversines, Dy_ff = hav(FC(i,s), FC(i,s-1)), for every row of the tile from LDS (two rows at a time)
         if (!col_emit) return;
+        if (hp.on && hp.south && ty == 0) emit_south<T, NT>(g, hp, o, rowoff(1));      // rows j <= 1 / j < 1 of this column
         double (*L)[R][64] = lds.v;
 #pragma unroll 1
         for (int r = 1; r < R; r += 2) {
@@ -657,8 +768,8 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
                         Nb{ L[L_FC + 0][rb - 1][lane], L[L_FC + 1][rb - 1][lane], L[L_FC + 2][rb - 1][lane] } };
             double dd2[2];
             hav_batch<2>(X, Y, Rad, dd2);
-            if (sa >= g.jm_lo) put32<T, NT>(o, TPG_DY_FF, rowoff(sa), dd2[0]);
-            if (two && sb >= g.jm_lo) put32<T, NT>(o, TPG_DY_FF, rowoff(sb), dd2[1]);
+            if (sa >= g.jm_lo) emit(TPG_DY_FF, 1, 1, true, sa, rowoff(sa), dd2[0]);
+            if (two && sb >= g.jm_lo) emit(TPG_DY_FF, 1, 1, true, sb, rowoff(sb), dd2[1]);
         }
         return;
     }
@@ -698,7 +809,7 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         A += at[1];
         A += at[2];
         A += at[3];
-        put32<T, NT>(o, k == 0 ? TPG_AZ_CC : TPG_AZ_FF, off, A * (Rad * Rad));
+        emit(k == 0 ? TPG_AZ_CC : TPG_AZ_FF, k, k, true, s, off, A * (Rad * Rad));
     }
 
     // 8 haversines in pairs; operand e = (x point, y point), each {lam, a, ca}
@@ -723,12 +834,12 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         hav_batch<1>(X, Y, Rad, dd1);
         d[6] = dd1[0];
     }
-    put32<T, NT>(o, TPG_DX_CC, off, d[0]); put32<T, NT>(o, TPG_DX_FC, off, d[1]);
-    put32<T, NT>(o, TPG_DX_CF, off, d[2]); put32<T, NT>(o, TPG_DX_FF, off, d[3]);
-    put32<T, NT>(o, TPG_DY_CC, off, d[4]); put32<T, NT>(o, TPG_DY_FC, off, d[5]);
-    put32<T, NT>(o, TPG_DY_CF, off, d[6]);
-    put32<T, NT>(o, TPG_AZ_FC, off, d[5] * d[1]);
-    put32<T, NT>(o, TPG_AZ_CF, off, d[6] * d[2]);
+    emit(TPG_DX_CC, 0, 0, true, s, off, d[0]); emit(TPG_DX_FC, 1, 0, true, s, off, d[1]);
+    emit(TPG_DX_CF, 0, 1, true, s, off, d[2]); emit(TPG_DX_FF, 1, 1, true, s, off, d[3]);
+    emit(TPG_DY_CC, 0, 0, true, s, off, d[4]); emit(TPG_DY_FC, 1, 0, true, s, off, d[5]);
+    emit(TPG_DY_CF, 0, 1, true, s, off, d[6]);
+    emit(TPG_AZ_FC, 1, 0, true, s, off, d[5] * d[1]);
+    emit(TPG_AZ_CF, 0, 1, true, s, off, d[6] * d[2]);
 }
 
 // ---- K2: halo cells of the 20 arrays ------------------------------------------------------------
@@ -845,28 +956,37 @@ template <typename T>
 int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStream_t s)
 {
     dim3 grid1(((g.Nx + 255) / 256) * (g.jm_hi - g.jm_lo + 1));
-    // knobs (tpg::config(), read once): TPG_CELLS_VARIANT 3 = k_cells_tile (default), 0 = k_cells (thread per cell,
-    // the cross-check: tests/test_gpu_variants.py); TPG_BUILD_NT 1 = streaming stores (default), 0 = plain stores
+    // knobs (tpg::config(), read once): TPG_CELLS_VARIANT 3 = k_cells_tile writing the halo cells too (default), 2 = k_cells_tile + k_halos
+    // (the round-5 default), 0 = k_cells (thread per cell) + k_halos -- the cross-checks: tests/test_gpu_variants.py;
+    // TPG_BUILD_NT 1 = streaming stores (default), 0 = plain stores
     const tpg::Config& cfg = tpg::config();
     const bool nt = cfg.build_nt;
     constexpr int R = 8;                                       // point rows per tile (16 = one block per CU: measured 25 % slower)
     const int nrows = g.jm_hi - g.jm_lo + 1;
-    const int tiles_x = (g.Nx + 61) / 62;
     const int tiles_y = (nrows + (R - 1) - 1) / (R - 1);
     const bool offsets32 = (unsigned long long)g.sx * (unsigned long long)(g.jend - g.jstart + 1 + 2 * g.Hy) * sizeof(T) < (1ull << 32);
-    if (cfg.cells_variant == 3 && tiles_y <= 65535 && offsets32) {     // tile rows ride on gridDim.y; stores use 32-bit byte offsets
+    const bool south_in_band = g.jstart - g.Hy <= 1;
+    HaloPush hp{ 0, g.Ny, 0, g.jstart - g.Hy };
+    if (cfg.cells_variant != 0 && tiles_y <= 65535 && offsets32) {     // tile rows ride on gridDim.y; stores use 32-bit byte offsets
+        // the tile kernel writes the halo cells itself wherever sources and images are distinct cells (TPG_CELLS_VARIANT=2: never -- K2 does)
+        if (cfg.cells_variant == 3 && g.Ny > 2 * g.Hy + 2 && g.Nx >= 2 * g.Hx + 2) {
+            hp.on = 1;
+            hp.jn_hi = g.jend + g.Hy > g.Ny ? (g.jend + g.Hy < g.Ny + g.Hy ? g.jend + g.Hy : g.Ny + g.Hy) : g.Ny;
+            hp.south = south_in_band ? 1 : 0;
+        }
+        const int tiles_x = ((hp.on ? g.sx : g.Nx) + 61) / 62;          // with the push the tile grid spans the x halos too
         dim3 gridt((unsigned)tiles_x, (unsigned)tiles_y);
-        if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x);
-        else    hipLaunchKernelGGL((k_cells_tile<T, false, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x);
+        if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x, hp);
+        else    hipLaunchKernelGGL((k_cells_tile<T, false, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x, hp);
     }
     else if (nt) hipLaunchKernelGGL((k_cells<T, true>), grid1, dim3(256), 0, s, g, o);
     else         hipLaunchKernelGGL((k_cells<T, false>), grid1, dim3(256), 0, s, g, o);
     int rc = tpg::launch_status("k_cells");
     if (rc) return rc;
+    if (hp.on) return TPG_OK;                                          // K0 + K1: every halo cell has been written
     // K3 rides in the K2 launch unless the grid is so short that a north-fold source row or the row-Ny
     // substitution could be a continuation row (then K3 must run after K2, as in the reference's order)
     HaloRegions hm = h;
-    const bool south_in_band = g.jstart - g.Hy <= 1;
     hm.merged_south = (south_in_band && g.Ny > 2 * g.Hy + 2) ? 1 : 0;
     if (hm.merged_south) hm.nC = (h.nsouth + 1) * g.sx;
     int nh = hm.nA + hm.nB + hm.nC + hm.nD;

@@ -26,12 +26,16 @@ def knob(osg, via_testlib):
 
 @pytest.mark.parametrize("kw", [dict(size=(250, 100, 1)),
                                 dict(size=(128, 64, 1), halo=(3, 2, 1), north_poles_latitude=65),
-                                dict(size=(64, 20, 1), dtype=torch.float32)], ids=["250x100", "128x64", "64x20-f32"])
+                                dict(size=(64, 20, 1), dtype=torch.float32),
+                                dict(size=(360, 180, 1), halo=(5, 5, 5)),                           # the reference's model halo
+                                dict(size=(60, 10, 1)),                                             # Ny = 2 Hy + 2: too short for the push (k_halos / k_south run)
+                                dict(size=(8, 40, 1), halo=(4, 2, 1))],                             # Nx < 2 Hx + 2: too narrow
+                         ids=["250x100", "128x64", "64x20-f32", "360x180-halo5", "60x10-short", "8x40-narrow"])
 def test_build_kernel_variants_agree(osg, gpu, knob, kw):
     kw = dict(kw)
     dtype = kw.pop("dtype", torch.float64)
     results = {}
-    for variant, nt in ((0, 1), (3, 1), (3, 0), (0, 0)):
+    for variant, nt in ((0, 1), (3, 1), (3, 0), (0, 0), (2, 1), (2, 0)):     # 3: tile kernel writes the halo cells too; 2: tile kernel + k_halos
         knob["TPG_CELLS_VARIANT"], knob["TPG_BUILD_NT"] = str(variant), str(nt)
         osg._lib.lib().tpg_reload_config()
         g = osg.TripolarGrid(osg.GPU(0), dtype, **kw)
