@@ -263,13 +263,16 @@ class HaloFillPlan:
             comm = getattr(arch, "rccl_comm", None) if (distributed and exchange is None) else None
             uniform = len(zip_fs) in (0, len(fs))
             calls, pending = [], None
+            if comm is not None:
+                # EVERY rank of the chain enters the agreement, before it picks its branch: a rank whose fields are not uniformly zipped takes
+                # the host-driven branch below, and its peers must not be left waiting in the collective for it
+                _agree_across_ranks(arch, (len(fs), geom[0], geom[2:], bool(pack_free), self._fields_per_stage),
+                                    "(fields, Nx, Nz + halos, pack_free, fields_per_stage) of a seam exchange")
             if comm is not None and uniform and (bool(zip_fs) == (arch.local_rank == arch.ranks[1] - 1)):
                 # the production path of a DistributedTripolarGrid: ONE C call per batch of <= TPG_MAX_FIELDS fields does the whole
                 # fill_halo_regions! -- zipper (last rank) -> periodic x -> RCCL seam exchange -- on the current stream
                 from .distributed import NORTH, SOUTH, SeamBuffers, exchange_plan, message_shape
                 plan = exchange_plan(arch.local_rank, arch.ranks[1])
-                _agree_across_ranks(arch, (len(fs), geom[0], geom[2:], bool(pack_free), self._fields_per_stage),
-                                    "(fields, Nx, Nz + halos, pack_free, fields_per_stage) of a seam exchange")
                 for b0 in range(0, len(fs), _lib.TPG_MAX_FIELDS):
                     batch = fs[b0:b0 + _lib.TPG_MAX_FIELDS]
                     xl, yl, sg = _tables(batch) if zip_fs else (None, None, None)
@@ -359,7 +362,24 @@ def halo_fill_plan(fields, *, exchange=None, pack_free=False, fields_per_stage=0
     return HaloFillPlan(fields, exchange=exchange, pack_free=pack_free, fields_per_stage=fields_per_stage)
 
 
+_PLANS_PER_FIELD = 8
+
+
 def fill_halo_regions(fields, *, exchange=None):
-    """fill_halo_regions!(fields...) on a tripolar grid: builds a HaloFillPlan and runs it once
-    (keep the plan and call it when the same fields are filled repeatedly)."""
-    return HaloFillPlan(fields, exchange=exchange)()
+    """fill_halo_regions!(fields...) on a tripolar grid.  The HaloFillPlan of a field list is built at its first fill and kept with the
+    list's first field (at most 8 per field; it goes when the field goes): a model fills the same tuples every (sub-)step, and on a
+    distributed grid building a plan costs one host-blocking agreement collective per geometry group -- paid once per field
+    list, not once per fill.  The key holds what a plan depends on -- the fields' identities, their tensors and boundary conditions, the
+    transport override --, so a field whose `data` or conditions were replaced gets a new plan."""
+    fs = [fields] if isinstance(fields, Field) else list(fields)
+    if not fs:
+        return None
+    key = (tuple((id(f), f.data.data_ptr(), id(f.boundary_conditions)) for f in fs), id(exchange), id(_lib.lib()))
+    cache = fs[0].__dict__.setdefault("_fill_plans", {})
+    plan = cache.get(key)
+    if plan is None:
+        plan = HaloFillPlan(fs, exchange=exchange)
+        if len(cache) >= _PLANS_PER_FIELD:
+            cache.pop(next(iter(cache)))
+        cache[key] = plan
+    return plan()

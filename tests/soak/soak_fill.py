@@ -20,7 +20,7 @@ for t in range(trials):
     nf = int(rng.integers(1, 6))
     dt, tdt, ft = ((np.float64, torch.float64, 1), (np.float32, torch.float32, 0))[t % 3 == 0]
     os.environ["TPG_ZIPPER_VARIANT"] = str(int(rng.choice([0, 3])))
-    mode = t % 3
+    mode = t % 4                                             # automatic / never fused / fused chunk items / fused one thread per cell
     if mode == 0: os.environ.pop("TPG_FILL_FUSED", None)
     else: os.environ["TPG_FILL_FUSED"] = str(mode - 1)
     os.environ["TPG_FILL_MERGED"] = str(int(rng.integers(0, 2)))

@@ -1,6 +1,6 @@
 """GPU box: extended randomised soak of tpg_build_grid against the oracle (bit-exact, whole padded arrays):
 sizes up to 400 x 120, continuous random poles / south / first-pole longitude / radius, both element types,
-both the tile and the marching kernels.  usage: python tests/soak/soak_grid.py [trials] [seed] [big]"""
+the tile kernel with and without its own halo writes, and the thread-per-cell kernel.  usage: python tests/soak/soak_grid.py [trials] [seed] [big]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -19,7 +19,7 @@ for t in range(trials):
               first_pole_longitude=float(np.round(rng.uniform(-200, 380), int(rng.integers(0, 6)))),
               southernmost_latitude=float(np.round(rng.uniform(-88, 15), int(rng.integers(0, 6)))), radius=float(rng.choice([1.0, 6371e3, 3389.5e3])))
     dtype, tdt = ((np.float64, torch.float64), (np.float32, torch.float32))[t % 5 == 0]
-    os.environ["TPG_CELLS_VARIANT"] = "3" if t % 3 else "0"; testlib.lib().tpg_reload_config()
+    os.environ["TPG_CELLS_VARIANT"] = ("0", "3", "2", "3")[t % 4]; testlib.lib().tpg_reload_config()      # 3: the tile kernel writes the halo cells too (default)
     ref = oracle.build_grid(dtype=dtype, **kw)
     g = osg.TripolarGrid(osg.GPU(0), tdt, **kw)
     for name, r in ref.items():

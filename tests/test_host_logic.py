@@ -247,3 +247,49 @@ def test_traffic_json_is_keyed_per_kernel_source():
         assert "k_cells_tile" not in stale and "k_tables" not in stale and ("k_fill_merged" in stale) == ("k_fill_merged" in live)
     finally:
         bench.sources_sha16 = saved
+
+
+def test_fill_halo_regions_keeps_its_plan_with_the_first_field(monkeypatch):
+    """fill_halo_regions(fields) used to build a new HaloFillPlan on every call -- on a distributed grid one host-blocking
+    agreement collective per geometry group per fill.  The plan of a field list is now built once and kept with the list's first field;
+    a replaced tensor or boundary condition, or another list, gets a plan of its own; at most 8 plans per field."""
+    import types
+    import orthogonalsphericalshellgrids.jl_amd.fields as F
+    built = []
+
+    class FakePlan:
+        def __init__(self, fields, exchange=None):
+            built.append([id(f) for f in fields])
+
+        def __call__(self):
+            return "filled"
+
+    monkeypatch.setattr(F, "HaloFillPlan", FakePlan)
+    monkeypatch.setattr(F._lib, "lib", lambda: F)                     # any stable object: the key only takes its identity
+
+    class T:                                                            # a tensor stand-in: the key reads data_ptr()
+        def __init__(self, p):
+            self.p = p
+
+        def data_ptr(self):
+            return self.p
+
+    def field(p):
+        f = F.Field.__new__(F.Field)
+        f.data, f.boundary_conditions = T(p), object()
+        return f
+    a, b = field(100), field(200)
+    assert F.fill_halo_regions([a, b]) == "filled" and F.fill_halo_regions((a, b)) == "filled" and len(built) == 1
+    assert F.fill_halo_regions(a) == "filled" and len(built) == 2          # another list: another plan (kept with `a` as well)
+    F.fill_halo_regions([a, b]); F.fill_halo_regions(a)
+    assert len(built) == 2
+    b.data = T(300)                                                     # a replaced tensor: the old plan holds the old one
+    F.fill_halo_regions([a, b])
+    assert len(built) == 3
+    a.boundary_conditions = object()
+    F.fill_halo_regions([a, b])
+    assert len(built) == 4
+    for k in range(12):                                                 # bounded: the oldest plans leave
+        F.fill_halo_regions([a, field(1000 + k)])
+    assert len(a.__dict__["_fill_plans"]) == 8
+    assert F.fill_halo_regions([]) is None

@@ -6,8 +6,10 @@
 // it -- could only ever run on a one-rank communicator whose peers are the rank itself.  With this shim behind the TEST library
 // (TPG_RCCL_LIBRARY, read by tools/libtripolar_hip_test.so only) the same calls run between several REAL processes that share one GPU:
 // distinct ranks, distinct data, both neighbours different, the pipelined stage groups matched across processes.  It validates OUR use of the
-// API (which buffer goes to which peer, group order, stage pairing, stream / event ordering around the groups) -- NOT RCCL, not xGMI, and
-// nothing about performance.  The product library never loads it (it binds librccl by its fixed names and reads no environment variable).
+// API (which buffer goes to which peer, group order, stage pairing, message sizes) -- NOT RCCL, not xGMI, nothing about performance, and NOT
+// the stream / event ordering around the groups: ncclGroupEnd here synchronises every operation's stream and moves the data with blocking
+// copies, so a missing event wait between `stream` and `comm_stream` cannot show (that ordering is exercised on the one-rank RCCL loop-back,
+// tools/rccl_selftest.py).  The product library never loads it (it binds librccl by its fixed names and reads no environment variable).
 //
 // HOW.  One POSIX shared-memory mailbox (one message at a time) per ordered pair (src, dst), created by whichever side gets there first;
 // host-staged: a send is hipMemcpy device -> mailbox once the previous message of the pair has been consumed, a receive is hipMemcpy mailbox ->
@@ -20,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <atomic>
+#include <dirent.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <stdio.h>
@@ -41,7 +44,8 @@ struct Mailbox {                                    // lives in shared memory
     std::atomic<unsigned long long> written;        // messages put in so far
     std::atomic<unsigned long long> read;           // messages taken out so far
     std::atomic<unsigned long long> bytes;          // size of the message in the slot
-    char pad[40];
+    std::atomic<unsigned long long> attached;       // processes that have mapped this mailbox (each end once): unlinked only when both have
+    char pad[32];
     char slot[1];
 };
 
@@ -72,6 +76,7 @@ Mailbox* mailbox(Comm* c, int src, int dst)
     close(fd);
     if (p == MAP_FAILED) return nullptr;
     Mailbox* m = static_cast<Mailbox*>(p);
+    m->attached.fetch_add(1);
     c->boxes[{ src, dst }] = m;
     return m;
 }
@@ -153,9 +158,25 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id)
     return ncclSuccess;
 }
 
+// mailboxes a killed rank left behind (96 MB of address space each, the touched pages resident): anything of ours older than 15 minutes
+static void sweep_stale_mailboxes()
+{
+    DIR* d = opendir("/dev/shm");
+    if (!d) return;
+    const time_t now = time(nullptr);
+    while (dirent* e = readdir(d)) {
+        if (strncmp(e->d_name, "tpgshim_", 8) != 0) continue;
+        std::string path = std::string("/dev/shm/") + e->d_name;
+        struct stat st;
+        if (stat(path.c_str(), &st) == 0 && now - st.st_mtime > 900) shm_unlink((std::string("/") + e->d_name).c_str());
+    }
+    closedir(d);
+}
+
 ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank)
 {
     if (!comm || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    if (rank == 0) sweep_stale_mailboxes();
     Comm* c = new Comm;
     c->rank = rank; c->nranks = nranks;
     id.internal[sizeof c->tag - 1] = 0;
@@ -169,10 +190,16 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
     Comm* c = reinterpret_cast<Comm*>(comm);
     if (!c) return ncclSuccess;
     for (auto& kv : c->boxes) {
+        // the name goes only once BOTH ends have mapped the object: a peer that has not opened it yet would otherwise create a fresh, empty
+        // one under the same name and never see what was sent.  (An end that leaves first keeps the name for the other; a mailbox whose
+        // peer never came is removed by the stale-object sweep of a later communicator.)
+        const bool both = kv.second->attached.load() >= 2;
         munmap(kv.second, sizeof(Mailbox) + kSlotBytes);
-        char name[96];
-        snprintf(name, sizeof name, "/tpgshim_%s_%d_%d", c->tag, kv.first.first, kv.first.second);
-        shm_unlink(name);                                              // both ends try; the second one finds it gone
+        if (both) {
+            char name[96];
+            snprintf(name, sizeof name, "/tpgshim_%s_%d_%d", c->tag, kv.first.first, kv.first.second);
+            shm_unlink(name);                                          // both ends try; the second one finds it gone
+        }
     }
     delete c;
     return ncclSuccess;
