@@ -139,14 +139,17 @@ def auxiliary(torch, osg, _lib, lib, tlib, testlib, dev, fields, fptrs, xl, yl, 
         ws2 = torch.empty(int(lib.tpg_build_grid_workspace_bytes(C.byref(p2))), dtype=torch.uint8, device=dev)
         for _ in range(3):
             _lib.check(lib.tpg_build_grid(C.byref(p2), ptr2, ws2.data_ptr(), ws2.numel(), stream))
-        b0, b1 = ev(), ev()
-        b0.record()
-        for _ in range(20):
-            _lib.check(lib.tpg_build_grid(C.byref(p2), ptr2, ws2.data_ptr(), ws2.numel(), stream))
-        b1.record(); torch.cuda.synchronize()
-        us2 = b0.elapsed_time(b1) / 20 * 1e3
+        batches = []                                                        # 3 batches of 20 back-to-back builds; the median batch is the figure
+        for _ in range(3):                                                  # (the FIRST use of freshly allocated arrays in the first GPU process of a
+            b0, b1 = ev(), ev()                                             # fresh box has shown a one-off ~40 ms stall inside a batch)
+            b0.record()
+            for _ in range(20):
+                _lib.check(lib.tpg_build_grid(C.byref(p2), ptr2, ws2.data_ptr(), ws2.numel(), stream))
+            b1.record(); torch.cuda.synchronize()
+            batches.append(b0.elapsed_time(b1) / 20 * 1e3)
+        us2 = statistics.median(batches)
         aux["config2_quarter_degree_build"] = {"size": [1440, 720, 1], "us_per_build": us2, "cells_per_s": 1440 * 720 / (us2 * 1e-6),
-                                               "store_GBps": 160.0 * 1448 * 728 / (us2 * 1e-6) / 1e9}
+                                               "store_GBps": 160.0 * 1448 * 728 / (us2 * 1e-6) / 1e9, "us_per_build_batches_of_20": batches}
         del out2, ws2
 
     def geometry():

@@ -43,7 +43,7 @@ def precompute_roofline(t_build_ms, evaluated_cells, band_cells, traffic, slowes
     tflops = FLOP_PER_CELL * evaluated_cells / (t_build_ms * 1e-3) / 1e12
     gbps = 160.0 * band_cells / (t_build_ms * 1e-3) / 1e9
     return {
-        "kernel": "tpg_build_grid (k_tables + k_cells_tile)" + (", slowest rank" if slowest_rank else ""), "bound": "fp64_valu",
+        "kernel": "tpg_build_grid (k_tables + k_cells_tile + k_halos)" + (", slowest rank" if slowest_rank else ""), "bound": "fp64_valu",
         "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
         "flop_per_cell": FLOP_PER_CELL, "evaluated_cells": evaluated_cells, "stored_cells": band_cells,
         "hbm_GBps": gbps, "hbm_frac": gbps / HBM_PEAK_GBPS,

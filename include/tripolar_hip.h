@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TPG_VERSION 500 /* 0.5.0 */
+#define TPG_VERSION 600 /* 0.6.0 */
 
 enum tpg_status {
     TPG_OK = 0,
@@ -107,7 +107,8 @@ const char *tpg_status_string(int status);
  * per-rank slicing of src/distributed_tripolar_grid.jl:36-73 without building the globe.
  *
  * out[q] (q = enum tpg_array): device array of (Nx+2Hx) x (jend-jstart+1+2Hy) elements of `ft`;
- * local row r (0-based) holds global row jstart-Hy+r.
+ * local row r (0-based) holds global row jstart-Hy+r.  Three launches: the 1-D tables (skipped with TPG_BUILD_TABLES_VALID), the cell
+ * kernel, the halo pass; every element of the 20 arrays is written.
  * workspace: device scratch of at least tpg_build_grid_workspace_bytes(p) bytes, 16-B aligned.
  */
 size_t tpg_build_grid_workspace_bytes(const tpg_params *p);
@@ -120,7 +121,8 @@ int tpg_build_grid(const tpg_params *p, void *const out[TPG_NUM_ARRAYS],
  * (src/zipper_boundary_condition.jl:146-155), i.e. fold_north_{center_center,face_center,
  * center_face,face_face}! (:70-138), dispatched on (xloc[f], yloc[f]); sign[f] is bc.condition
  * (ZipperBoundaryCondition(sign), :52).  All `nfields` fields share one geometry and are folded
- * by ONE kernel launch (batched pointer table, up to TPG_MAX_FIELDS per launch; more are split).
+ * by ONE kernel launch (batched pointer table, up to TPG_MAX_FIELDS per launch; more are split), whatever the halo width and
+ * whether or not the fields are 16-B aligned (any pointer aligned to the element type is accepted).
  * Levels k = kstart .. kstart+kcount-1 (1-based, may include halo levels 1-Hz..Nz+Hz).
  * In place; halo columns i<1, i>Nx are left to the periodic pass, as in the reference.
  */
@@ -157,9 +159,11 @@ int tpg_periodic_x_fill(void *const fields[], int nfields,
  * 143-147,177-185), then periodic x.  Small fields (2-D free-surface / barotropic fields: fewer than 2^20
  * written cells per call) take ONE fused launch in which every written cell is computed from original
  * interior values through the composed index map; results are identical to the two-launch sequence.
- * Large fields with 16-B chunkable rows and Hy <= 8 take ONE merged launch as well: column-chunk fold blocks that also
- * write the corner cells (composed map) beside periodic-x blocks for all other rows;
- * everything else runs tpg_zipper_fill then tpg_periodic_x_fill. */
+ * Large fields with Hy <= 8 take ONE merged launch as well: column-chunk fold blocks that also
+ * write the corner cells (composed map) beside periodic-x blocks for all other rows -- for EVERY halo width and every element-aligned
+ * pointer: 16-B aligned chunks where Hx and Nx are whole numbers of them (the default halo 4), the same chunks stored element-aligned
+ * otherwise (an odd Hx such as the halo (5, 5, 5) of examples/bickley_jet.jl:21, Float32 with Nx = 2 mod 4, 8-B aligned fields).
+ * Only Hy > 8 on a large field, Nx < 2 Hx + 2 or Ny < 2 Hy + 2 run tpg_zipper_fill then tpg_periodic_x_fill (two launches). */
 int tpg_fill_halo_regions(void *const fields[], int nfields,
                           const int8_t xloc[], const int8_t yloc[], const int32_t sign[],
                           int Nx, int Ny, int Nz, int Hx, int Hy, int Hz,

@@ -8,8 +8,10 @@
  *
  * Knobs (environment; read ONCE, at the first call into the test library, into an immutable record; tpg_reload_config()
  * re-reads them; every setting gives identical results, tests/test_gpu_variants.py):
- *    TPG_CELLS_VARIANT        cell kernel of tpg_build_grid: 3 LDS tile, halo cells pushed by the producing thread (default: two launches per
- *                             build), 2 LDS tile + the halo pass k_halos (the round-5 default), 0 thread per cell + k_halos (cross-check)
+ *    TPG_CELLS_VARIANT        cell kernel of tpg_build_grid: 2 LDS tile + the halo pass k_halos (default, the product's form), 3 LDS tile with
+ *                             the halo cells pushed by the producing thread (k_cells_tile_push: two launches per build instead of three;
+ *                             compiled into the TEST library only -- measured in round 6, not adopted: profiles/r06/build_push_ab.txt),
+ *                             0 thread per cell + k_halos (cross-check)
  *    TPG_BUILD_NT             1 streaming stores in tpg_build_grid (default), 0 plain stores
  *    TPG_ZIPPER_VARIANT       3 column work items (default), 0 row work items (the fallback kernels, everywhere)
  *    TPG_FILL_FUSED           0 never / 1 always (where valid) use the fused small-field fill; 2 = always, in its one-thread-per-cell form

@@ -32,7 +32,7 @@ static int env_int(const char* name, int dflt)
 static const Config* read_config()
 {
     Config* c = new Config;         // a few bytes per (re)load, never freed: readers may still hold the old record
-    { const int v = env_int("TPG_CELLS_VARIANT", 3); c->cells_variant = (v == 0 || v == 2) ? v : 3; }
+    { const int v = env_int("TPG_CELLS_VARIANT", 2); c->cells_variant = (v == 0 || v == 3) ? v : 2; }
     c->build_nt = env_int("TPG_BUILD_NT", 1) != 0;
     c->zipper_variant = env_int("TPG_ZIPPER_VARIANT", 3) == 0 ? 0 : 3;
     c->fill_fused = env_int("TPG_FILL_FUSED", -1);
@@ -58,7 +58,7 @@ const Config& config()
 // the product library has no knobs: one constant record, no environment access
 const Config& config()
 {
-    static const Config k{ 3, true, 3, -1, -1, false, -1, nullptr };
+    static const Config k{ 2, true, 3, -1, -1, false, -1, nullptr };
     return k;
 }
 #endif

@@ -46,7 +46,8 @@ int check_geom(int Nx, int Ny, int Nz, int Hx, int Hy, int Hz, int ft);
 // environment access.  The test library (libtripolar_hip_test.so, -DTPG_TEST_ABI) reads the TPG_* cross-check knobs of
 // include/tripolar_hip_test.h from the environment once into an immutable record; tpg_reload_config() publishes a fresh one.
 struct Config {
-    int cells_variant;        // TPG_CELLS_VARIANT  3 LDS-tile kernel that also writes the halo cells (default), 2 LDS-tile kernel + k_halos, 0 thread-per-cell cross-check
+    int cells_variant;        // TPG_CELLS_VARIANT  2 LDS-tile kernel + k_halos (default; the product's only form), 3 LDS-tile kernel that also writes the
+                              //                    halo cells (k_cells_tile_push, test library only), 0 thread-per-cell cross-check
     bool build_nt;            // TPG_BUILD_NT       1 streaming stores in tpg_build_grid (default), 0 plain
     int zipper_variant;       // TPG_ZIPPER_VARIANT 3 column items (default), 0 row items (the fallback kernels)
     int fill_fused;           // TPG_FILL_FUSED     -1 automatic (default), 0 never, 1 wherever valid, 2 wherever valid in the one-thread-per-cell form

@@ -27,12 +27,11 @@
 //                    tile form's 499 us at 1/10 degree; removed, history in DESIGN.md 4.)
 //   K2 halos       : compact pass over halo cells only (x-halo columns, north fold rows, zero
 //                    south rows of the coordinates, row-Ny substitution of the y-Center metrics).
-//                    Since round 6 the tile kernel PUSHES these cells itself (HaloPush below: the thread that
-//                    produces a value also stores its periodic, fold and substitution images, the south
-//                    tiles' apron waves the zero / continuation rows), so the default build is K0 + K1;
-//                    K2 / K3 remain for the thread-per-cell form, for grids too short or narrow for the
-//                    images to be distinct cells (Ny <= 2 Hy + 2, Nx < 2 Hx + 2), and as the cross-check
-//                    (TPG_CELLS_VARIANT=2: tile kernel + K2, the round-5 default).
+//                    Round 6 built the alternative -- the tile kernel PUSHES these cells itself (HaloPush below), K0 + K1
+//                    is then the whole build -- and measured it against this sequence: it saves 0.3-2.8 us per build
+//                    inside one binary and nothing against the round-5 binary (the 1/10 degree globe: + 1.7 %).  It is
+//                    kept in the TEST library (TPG_CELLS_VARIANT=3, k_cells_tile_push) as a bit-identical variant; the
+//                    product builds with K0 + K1 + K2.
 //   K3 south       : lat-lon continuation rows j = 1-Hy..1 of the 12 metrics (south rank only).
 //
 // No inter-rank communication: seam halo rows are the neighbour's interior rows of the same
@@ -314,8 +313,10 @@ struct HaloPush {
 
 // value v of array q (location xl, yl; metric or coordinate; all four compile-time constants at the call sites) produced at the interior cell
 // (i, j), whose own cell is at byte offset boff: the own cell and every image of it, as saddr stores at offsets derived from boff.  The images
-// are PLAIN stores whatever NT says: they are 32-40 B pieces of a line (a few lanes of the wave), which a streaming store would send past
-// the L2 as partial-line writes.  Inlined:
+// carry the SAME streaming hint as the own-cell stores: where the compiler sinks the stores of the edge and the non-edge branch of a site
+// into one instruction it keeps a hint only if both had it, and a first version with plain image stores silently turned 11 of the 21 stores
+// of the NON-edge path into plain ones -- the 1 GB then stayed behind as dirty lines and the next kernel on the stream (the halo fill of a
+// bench step) ran 67 instead of 47 us (profiles/r06/build_push_ab.txt; tests/test_abi.py now counts the plain stores of the kernel).  Inlined:
 // a few integer operations and predicated stores per site, in edge tiles only (a first version behind a noinline call, with g / o copied to
 // scratch for it, ran the 1/4 degree build at 344 us instead of 102: profiles/r06/build_push_ab.txt).
 template <typename T, bool NT>
@@ -334,16 +335,16 @@ __device__ __forceinline__ void emit_edge(const GridK& g, const HaloPush& hp, co
     if (i < 1 || i > Nx) return;                                              // images are pushed from the interior instance of a column only
     if (rowNyC && ipart > Nx / 2 && ipart <= Nx && ipart != i) {
         const unsigned b2 = boff + (unsigned)((ipart - i) * sz);
-        put32<T, false>(o, q, b2, v);
-        if (ipart > Nx - Hx) put32<T, false>(o, q, b2 - pw, v);
+        put32<T, NT>(o, q, b2, v);
+        if (ipart > Nx - Hx) put32<T, NT>(o, q, b2 - pw, v);
     }
     const int dj = Ny - j + yl;                                              // fold image row Ny + dj: (Ny + dj) - j = 2 dj - yl rows up
     if (dj >= 1 && Ny + dj <= hp.jn_hi) {
         const int iwd = ipart > Nx ? ipart - Nx : ipart;
         const unsigned b3 = boff + (unsigned)(((iwd - i) + g.sx * (2 * dj - yl)) * sz);
-        put32<T, false>(o, q, b3, v);
-        if (iwd <= Hx) put32<T, false>(o, q, b3 + pw, v);
-        if (iwd > Nx - Hx) put32<T, false>(o, q, b3 - pw, v);
+        put32<T, NT>(o, q, b3, v);
+        if (iwd <= Hx) put32<T, NT>(o, q, b3 + pw, v);
+        if (iwd > Nx - Hx) put32<T, NT>(o, q, b3 - pw, v);
     }
 }
 
@@ -670,7 +671,7 @@ __device__ __forceinline__ void hav_batch(const Nb (&X)[N], const Nb (&Y)[N], do
 }
 
 template <typename T, bool NT, int R>
-__global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, int tiles_x, HaloPush hp)
+__global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, int tiles_x)
 {
     __shared__ __attribute__((aligned(16))) double atabs[R][TPG_ATAN_TABLE_DOUBLES];
     __shared__ TileLds<R> lds;
@@ -686,30 +687,182 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
     // Tile rows are dispatched in blockIdx.y order: NORTH to SOUTH, so that the one slow row of a launch -- row Ny, whose wave takes the
     // general (scalar) path through coord(): +2.2 us of block latency -- starts first instead of ending the launch.  Worth ~0.3 % at
     // 1/10 degree (in-process A/B, round 4: 505.7 -> 504.2 us per build, i.e. inside the noise); kept because it costs nothing.
-    // With the halo push (hp.on) the EDGE tile rows carry extra stores and must not be the last blocks of the launch, where their extra time
-    // would add to the kernel's: the southernmost tile row is dispatched right after the northernmost, the others follow north to south.
-    int ty = (int)gridDim.y - 1 - (int)blockIdx.y;
+    const int ty = (int)gridDim.y - 1 - (int)blockIdx.y;
     const int tx = blockIdx.x;
-    if (hp.on) {
-        const int ny_t = (int)gridDim.y, by = (int)blockIdx.y;
-        ty = by == 0 ? ny_t - 1 : (by == 1 ? 0 : ny_t - by);
+    const int s0 = g.jm_lo - 1 + ty * (R - 1);
+    const int s = s0 + p;                                                    // this wave's step
+    int i = tx * 62 + lane;
+    const bool col_emit = lane >= 1 && lane <= 62 && i <= g.Nx;
+    if (i > g.Nx + 1) i = g.Nx + 1;
+    const double Rad = g.R;
+    const bool active_row = s <= g.jm_hi;                                    // rows past the band: idle waves
+    const unsigned col = (unsigned)(i + g.Hx - 1);
+    auto rowoff = [&](int j) -> unsigned { return (col + (unsigned)g.sx * (unsigned)(j - g.jstart + g.Hy)) * (unsigned)sizeof(T); };   // bytes
+
+    // ---- phase 1: one point set per thread
+    Step4 q;
+    if (active_row) {
+        const bool fast = s >= 1 && s < g.Ny && absD(g.fplp90) <= 360.0;     // wave-uniform
+        if (fast) {
+            LaneConst lc;
+            const int iw = i < 1 ? i + g.Nx : (i > g.Nx ? i - g.Nx : i);
+            int i0 = iw - g.shift; if (i0 < 1) i0 += g.Nx;
+            lc.aslF = g.ti[0 * g.Nx + iw - 1]; lc.aclF = g.ti[1 * g.Nx + iw - 1];
+            lc.aslC = g.ti[2 * g.Nx + iw - 1]; lc.aclC = g.ti[3 * g.Nx + iw - 1];
+            lc.hemi = (i0 <= g.Nx / 2) ? -90.0 : 90.0;
+            points_fast2(g, lc, load_rowtab(g, s, s + 1), q, atab);
+        } else {
+            Step4 tmp; GridK gc = g; points_general(gc, i, s, s + 1, tmp); q = tmp;
+        }
+        // coordinates: rows p >= 1 emit CC/FC(s) and FF/CF(s+1); the first tile's apron row emits FF/CF(jm_lo)
+        if (col_emit) {
+            if (p >= 1 && s >= g.jm_lo) {
+                unsigned off = rowoff(s);
+                put32<T, NT>(o, TPG_LAMBDA_FC, off, q.lam[0]); put32<T, NT>(o, TPG_PHI_FC, off, q.phi[0]);
+                put32<T, NT>(o, TPG_LAMBDA_CC, off, q.lam[1]); put32<T, NT>(o, TPG_PHI_CC, off, q.phi[1]);
+            }
+            if ((p >= 1 || ty == 0) && s + 1 >= g.jm_lo && s + 1 <= g.jm_hi) {
+                unsigned off1 = rowoff(s + 1);
+                put32<T, NT>(o, TPG_LAMBDA_FF, off1, q.lam[2]); put32<T, NT>(o, TPG_PHI_FF, off1, q.phi[2]);
+                put32<T, NT>(o, TPG_LAMBDA_CF, off1, q.lam[3]); put32<T, NT>(o, TPG_PHI_CF, off1, q.phi[3]);
+            }
+        }
+        double (*L)[R][64] = lds.v;
+        L[L_FC + 0][p][lane] = q.lam[0]; L[L_FC + 1][p][lane] = q.a[0]; L[L_FC + 2][p][lane] = q.ca[0];
+        L[L_CC + 0][p][lane] = q.lam[1]; L[L_CC + 1][p][lane] = q.a[1]; L[L_CC + 2][p][lane] = q.ca[1];
+        L[L_CC + 3][p][lane] = q.X[0];   L[L_CC + 4][p][lane] = q.Y[0]; L[L_CC + 5][p][lane] = q.Z[0];
+        L[L_FF + 0][p][lane] = q.lam[2]; L[L_FF + 1][p][lane] = q.a[2]; L[L_FF + 2][p][lane] = q.ca[2];
+        L[L_FF + 3][p][lane] = q.X[1];   L[L_FF + 4][p][lane] = q.Y[1]; L[L_FF + 5][p][lane] = q.Z[1];
+        L[L_CF + 0][p][lane] = q.lam[3]; L[L_CF + 1][p][lane] = q.a[3]; L[L_CF + 2][p][lane] = q.ca[3];
     }
+    __syncthreads();                                                         // the only barrier: point sets in LDS
+    if (p == 0) {
+        // The apron wave has no cell row of its own: instead of idling through phase 2 it computes one of the
+        // eight haversines, Dy_ff = hav(FC(i,s), FC(i,s-1)), for every row of the tile from LDS (two rows at a time)
+        if (!col_emit) return;
+        double (*L)[R][64] = lds.v;
+#pragma unroll 1
+        for (int r = 1; r < R; r += 2) {
+            const int sa = s0 + r, sb = sa + 1;
+            if (sa > g.jm_hi) break;
+            const bool two = (r + 1 < R) && sb <= g.jm_hi;
+            const int rb = two ? r + 1 : r;
+            Nb X[2] = { Nb{ L[L_FC + 0][r][lane], L[L_FC + 1][r][lane], L[L_FC + 2][r][lane] },
+                        Nb{ L[L_FC + 0][rb][lane], L[L_FC + 1][rb][lane], L[L_FC + 2][rb][lane] } };
+            Nb Y[2] = { Nb{ L[L_FC + 0][r - 1][lane], L[L_FC + 1][r - 1][lane], L[L_FC + 2][r - 1][lane] },
+                        Nb{ L[L_FC + 0][rb - 1][lane], L[L_FC + 1][rb - 1][lane], L[L_FC + 2][rb - 1][lane] } };
+            double dd2[2];
+            hav_batch<2>(X, Y, Rad, dd2);
+            if (sa >= g.jm_lo) put32<T, NT>(o, TPG_DY_FF, rowoff(sa), dd2[0]);
+            if (two && sb >= g.jm_lo) put32<T, NT>(o, TPG_DY_FF, rowoff(sb), dd2[1]);
+        }
+        return;
+    }
+    if (!active_row || s < g.jm_lo || !col_emit) return;                    // idle rows and apron lanes are done
+
+    // ---- phase 2: the cell (i, s) from own registers + LDS neighbours, loaded just in time so that the
+    //      live set stays under 128 VGPRs (4 waves/SIMD supply the ILP; batches of 2 suffice)
+    double (*L)[R][64] = lds.v;
+    const int pm = p - 1, le = lane + 1, lw = lane - 1;
+    const unsigned off = rowoff(s);
+
+    // 2 spherical quadrilaterals first (unit vectors only): Az_cc from FF points, Az_ff from CC points
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        V3 a, b, c, dd;
+        if (k == 0) {   // ffP = FF(i,s), ffEP = FF(i+1,s), ffE = FF(i+1,s+1), ff = FF(i,s+1)
+            a = V3{ L[L_FF + 3][pm][lane], L[L_FF + 4][pm][lane], L[L_FF + 5][pm][lane] };
+            b = V3{ L[L_FF + 3][pm][le], L[L_FF + 4][pm][le], L[L_FF + 5][pm][le] };
+            c = V3{ L[L_FF + 3][p][le], L[L_FF + 4][p][le], L[L_FF + 5][p][le] };
+            dd = V3{ q.X[1], q.Y[1], q.Z[1] };
+        } else {        // ccWP = CC(i-1,s-1), ccP = CC(i,s-1), cc = CC(i,s), ccW = CC(i-1,s)
+            a = V3{ L[L_CC + 3][pm][lw], L[L_CC + 4][pm][lw], L[L_CC + 5][pm][lw] };
+            b = V3{ L[L_CC + 3][pm][lane], L[L_CC + 4][pm][lane], L[L_CC + 5][pm][lane] };
+            c = V3{ q.X[0], q.Y[0], q.Z[0] };
+            dd = V3{ L[L_CC + 3][p][lw], L[L_CC + 4][p][lw], L[L_CC + 5][p][lw] };
+        }
+        double tt[4], at[4];
+        tt[0] = tri_tan_nr(a, b, c); tt[1] = tri_tan_nr(a, b, dd);
+        tt[2] = tri_tan_nr(a, c, dd); tt[3] = tri_tan_nr(b, c, dd);
+        if (__any(tpgb::atan_small_b<4>(tt, at))) {                 // wave-uniform fallback (large or degenerate triangles)
+            tt[0] = tri_tan(a, b, c); tt[1] = tri_tan(a, b, dd); tt[2] = tri_tan(a, c, dd); tt[3] = tri_tan(b, c, dd);
+            tpgb::atan_b<4>(tt, at);
+        }
+        // (2 t0 + 2 t1 + 2 t2 + 2 t3) / 2, summed left to right, is t0 + t1 + t2 + t3 summed left to right: doubling and halving are
+        // exact and commute with every rounding (no overflow / underflow at these magnitudes) -- 5 multiplications less per quadrilateral
+        double A = at[0];
+        A += at[1];
+        A += at[2];
+        A += at[3];
+        put32<T, NT>(o, k == 0 ? TPG_AZ_CC : TPG_AZ_FF, off, A * (Rad * Rad));
+    }
+
+    // 8 haversines in pairs; operand e = (x point, y point), each {lam, a, ca}
+    //   0 dxcc(fcE,fc) 1 dxfc(cc,ccW) 2 dxcf(ffEP,ffP) 3 dxff(cfP,cfWP) 4 dycc(cf,cfP) 5 dyfc(ff,ffP) 6 dycf(cc,ccP) 7 dyff(fc,fcP)
+    auto ld = [&](int f, int pp, int ll) -> Nb { return Nb{ L[f + 0][pp][ll], L[f + 1][pp][ll], L[f + 2][pp][ll] }; };
+    const Nb own[4] = { Nb{ q.lam[0], q.a[0], q.ca[0] }, Nb{ q.lam[1], q.a[1], q.ca[1] },
+                        Nb{ q.lam[2], q.a[2], q.ca[2] }, Nb{ q.lam[3], q.a[3], q.ca[3] } };   // fc cc ff cf
+    double d[8];
+#pragma unroll
+    for (int hb = 0; hb < 6; hb += 2) {
+        Nb X[2], Y[2];
+        if (hb == 0)      { X[0] = ld(L_FC, p, le); Y[0] = own[0];            X[1] = own[1];            Y[1] = ld(L_CC, p, lw); }
+        else if (hb == 2) { X[0] = ld(L_FF, pm, le); Y[0] = ld(L_FF, pm, lane); X[1] = ld(L_CF, pm, lane); Y[1] = ld(L_CF, pm, lw); }
+        else              { X[0] = own[3];           Y[0] = ld(L_CF, pm, lane); X[1] = own[2];            Y[1] = ld(L_FF, pm, lane); }
+        double dd2[2];
+        hav_batch<2>(X, Y, Rad, dd2);
+        d[hb] = dd2[0]; d[hb + 1] = dd2[1];
+    }
+    {   // Dy_cf here; Dy_ff is the apron wave's
+        Nb X[1] = { own[1] }, Y[1] = { ld(L_CC, pm, lane) };
+        double dd1[1];
+        hav_batch<1>(X, Y, Rad, dd1);
+        d[6] = dd1[0];
+    }
+    put32<T, NT>(o, TPG_DX_CC, off, d[0]); put32<T, NT>(o, TPG_DX_FC, off, d[1]);
+    put32<T, NT>(o, TPG_DX_CF, off, d[2]); put32<T, NT>(o, TPG_DX_FF, off, d[3]);
+    put32<T, NT>(o, TPG_DY_CC, off, d[4]); put32<T, NT>(o, TPG_DY_FC, off, d[5]);
+    put32<T, NT>(o, TPG_DY_CF, off, d[6]);
+    put32<T, NT>(o, TPG_AZ_FC, off, d[5] * d[1]);
+    put32<T, NT>(o, TPG_AZ_CF, off, d[6] * d[2]);
+}
+
+#ifdef TPG_TEST_ABI
+// The tile body of the halo-push form (k_cells_tile_push below, TEST library only): the tile kernel k_cells_tile, with the tile grid spanning
+// the x halos; MODE 1 = the ordinary tiles, MODE 2 = the EDGE tile rows (north: fold images + row-Ny substitution; south: zero /
+// continuation rows) -- chosen once per block, at the top of the kernel, from block-uniform values.  A COPY of k_cells_tile's body on
+// purpose: sharing one templated body with the product's kernel cost that kernel 1.7-2 % on the 1/10 degree build (same-box A/B against
+// the round-5 binary, profiles/r06/build_push_ab.txt), so the product's kernel below is left exactly as it was.  The structs come BY VALUE:
+// by reference the kernel arguments left the SGPRs (+19 %).
+template <typename T, bool NT, int R, int MODE>
+__device__ __forceinline__ void cells_tile_body(const GridK g, const OutPtrs o, const int tiles_x, const HaloPush hp, const int ty,
+                                                double (&atabs)[R][TPG_ATAN_TABLE_DOUBLES], TileLds<R>& lds)
+{
+    constexpr bool PUSH = MODE != 0, EDGE = MODE == 2;
+    const int lane = threadIdx.x & 63;
+    const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);         // point row of this wave
+    // one copy of the atan interval table per wave: its load overlaps the lane's other table loads and
+    // needs no block barrier (LDS operations of one wave execute in order)
+    double* atab = atabs[p];
+    tpgb::atan_table_init(atab, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int tx = blockIdx.x;
     const int s0 = g.jm_lo - 1 + ty * (R - 1);
     const int s = s0 + p;                                                    // this wave's step
     // columns: 1 .. Nx -- or, with the halo push, 1-Hx .. Nx+Hx: the x-halo columns are cells of the tile grid (wrapped below)
-    const int i_hi = hp.on ? g.Nx + g.Hx : g.Nx;
-    int i = tx * 62 + lane - (hp.on ? g.Hx : 0);
+    const int i_hi = PUSH ? g.Nx + g.Hx : g.Nx;
+    int i = tx * 62 + lane - (PUSH ? g.Hx : 0);
     const bool col_emit = lane >= 1 && lane <= 62 && i <= i_hi;
     if (i > i_hi + 1) i = i_hi + 1;
     const double Rad = g.R;
     const bool active_row = s <= g.jm_hi;                                    // rows past the band: idle waves
     const unsigned col = (unsigned)(i + g.Hx - 1);
     auto rowoff = [&](int j) -> unsigned { return (col + (unsigned)g.sx * (unsigned)(j - g.jstart + g.Hy)) * (unsigned)sizeof(T); };   // bytes
-    // EDGE tiles also store the halo images of what they produce (HaloPush above); block-uniform, so every other tile runs the code it ran
-    // before.  emit(): array q at location (xl, yl), row j -- the plain store, or (edge tiles) own cell + images.
-    const bool edge = hp.on && (s0 + R >= g.Ny - g.Hy || (hp.south && ty == 0));
+    // emit(): array q at location (xl, yl), row j -- the plain store, or (EDGE tiles) own cell + halo images (HaloPush above)
     auto emit = [&](int q, int xl, int yl, bool metric, int j, unsigned boff, double v) {
-        if (edge) emit_edge<T, NT>(g, hp, o, q, xl, yl, metric, i, j, boff, v);
+        if constexpr (EDGE) emit_edge<T, NT>(g, hp, o, q, xl, yl, metric, i, j, boff, v);
         else put32<T, NT>(o, q, boff, v);
     };
 
@@ -754,7 +907,7 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
         // The apron wave has no cell row of its own: instead of idling through phase 2 it computes one of the
         // eight haversines, Dy_ff = hav(FC(i,s), FC(i,s-1)), for every row of the tile from LDS (two rows at a time)
         if (!col_emit) return;
-        if (hp.on && hp.south && ty == 0) emit_south<T, NT>(g, hp, o, rowoff(1));      // rows j <= 1 / j < 1 of this column
+        if constexpr (EDGE) { if (hp.south && ty == 0) emit_south<T, NT>(g, hp, o, rowoff(1)); }      // rows j <= 1 / j < 1 of this column
         double (*L)[R][64] = lds.v;
 #pragma unroll 1
         for (int r = 1; r < R; r += 2) {
@@ -841,6 +994,23 @@ __global__ __launch_bounds__(64 * R, 4) void k_cells_tile(GridK g, OutPtrs o, in
     emit(TPG_AZ_FC, 1, 0, true, s, off, d[5] * d[1]);
     emit(TPG_AZ_CF, 0, 1, true, s, off, d[6] * d[2]);
 }
+
+// The halo-push form (TPG_CELLS_VARIANT=3, test library only -- see the verdict on it at HaloPush above): K0 + this kernel is the whole build.
+template <typename T, bool NT, int R>
+__global__ __launch_bounds__(64 * R, 4) void k_cells_tile_push(GridK g, OutPtrs o, int tiles_x, HaloPush hp)
+{
+    __shared__ __attribute__((aligned(16))) double atabs[R][TPG_ATAN_TABLE_DOUBLES];
+    __shared__ TileLds<R> lds;
+    // the EDGE tile rows carry extra stores and must not be the last blocks of the launch, where their extra time would add to the
+    // kernel's: the southernmost tile row is dispatched right after the northernmost, the others follow north to south
+    const int ny_t = (int)gridDim.y, by = (int)blockIdx.y;
+    const int ty = by == 0 ? ny_t - 1 : (by == 1 ? 0 : ny_t - by);
+    // EDGE tile rows (block-uniform): those that reach row Ny - Hy (fold images, row-Ny substitution) and the southernmost one (south rows)
+    const bool edge = g.jm_lo - 1 + ty * (R - 1) + R >= g.Ny - g.Hy || (hp.south && ty == 0);
+    if (edge) cells_tile_body<T, NT, R, 2>(g, o, tiles_x, hp, ty, atabs, lds);
+    else      cells_tile_body<T, NT, R, 1>(g, o, tiles_x, hp, ty, atabs, lds);
+}
+#endif
 
 // ---- K2: halo cells of the 20 arrays ------------------------------------------------------------
 // x/y location of array q (order of enum tpg_array)
@@ -956,9 +1126,9 @@ template <typename T>
 int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStream_t s)
 {
     dim3 grid1(((g.Nx + 255) / 256) * (g.jm_hi - g.jm_lo + 1));
-    // knobs (tpg::config(), read once): TPG_CELLS_VARIANT 3 = k_cells_tile writing the halo cells too (default), 2 = k_cells_tile + k_halos
-    // (the round-5 default), 0 = k_cells (thread per cell) + k_halos -- the cross-checks: tests/test_gpu_variants.py;
-    // TPG_BUILD_NT 1 = streaming stores (default), 0 = plain stores
+    // knobs (tpg::config(), read once; test library): TPG_CELLS_VARIANT 2 = k_cells_tile + k_halos (default, and the product's only form),
+    // 3 = k_cells_tile_push (the tile kernel writes the halo cells too: one launch less; measured, not adopted -- HaloPush above),
+    // 0 = k_cells (thread per cell) + k_halos -- the cross-checks: tests/test_gpu_variants.py; TPG_BUILD_NT 1 = streaming stores (default), 0 = plain
     const tpg::Config& cfg = tpg::config();
     const bool nt = cfg.build_nt;
     constexpr int R = 8;                                       // point rows per tile (16 = one block per CU: measured 25 % slower)
@@ -966,24 +1136,29 @@ int launch_build(const GridK& g, const OutPtrs& o, const HaloRegions& h, hipStre
     const int tiles_y = (nrows + (R - 1) - 1) / (R - 1);
     const bool offsets32 = (unsigned long long)g.sx * (unsigned long long)(g.jend - g.jstart + 1 + 2 * g.Hy) * sizeof(T) < (1ull << 32);
     const bool south_in_band = g.jstart - g.Hy <= 1;
-    HaloPush hp{ 0, g.Ny, 0, g.jstart - g.Hy };
-    if (cfg.cells_variant != 0 && tiles_y <= 65535 && offsets32) {     // tile rows ride on gridDim.y; stores use 32-bit byte offsets
-        // the tile kernel writes the halo cells itself wherever sources and images are distinct cells (TPG_CELLS_VARIANT=2: never -- K2 does)
-        if (cfg.cells_variant == 3 && g.Ny > 2 * g.Hy + 2 && g.Nx >= 2 * g.Hx + 2) {
-            hp.on = 1;
-            hp.jn_hi = g.jend + g.Hy > g.Ny ? (g.jend + g.Hy < g.Ny + g.Hy ? g.jend + g.Hy : g.Ny + g.Hy) : g.Ny;
-            hp.south = south_in_band ? 1 : 0;
-        }
-        const int tiles_x = ((hp.on ? g.sx : g.Nx) + 61) / 62;          // with the push the tile grid spans the x halos too
+    const bool tile = cfg.cells_variant != 0 && tiles_y <= 65535 && offsets32;     // tile rows ride on gridDim.y; stores use 32-bit byte offsets
+#ifdef TPG_TEST_ABI
+    // TPG_CELLS_VARIANT=3: the tile kernel writes the halo cells itself wherever sources and images are distinct cells
+    if (tile && cfg.cells_variant == 3 && g.Ny > 2 * g.Hy + 2 && g.Nx >= 2 * g.Hx + 2) {
+        HaloPush hp{ 1, g.Ny, south_in_band ? 1 : 0, g.jstart - g.Hy };
+        if (g.jend + g.Hy > g.Ny) hp.jn_hi = g.jend + g.Hy < g.Ny + g.Hy ? g.jend + g.Hy : g.Ny + g.Hy;
+        const int tiles_xp = (g.sx + 61) / 62;                           // the tile grid spans the x halos too
+        dim3 gridp((unsigned)tiles_xp, (unsigned)tiles_y);
+        if (nt) hipLaunchKernelGGL((k_cells_tile_push<T, true, R>), gridp, dim3(64 * R), 0, s, g, o, tiles_xp, hp);
+        else    hipLaunchKernelGGL((k_cells_tile_push<T, false, R>), gridp, dim3(64 * R), 0, s, g, o, tiles_xp, hp);
+        return tpg::launch_status("k_cells_tile_push");                 // K0 + K1: every halo cell has been written
+    }
+#endif
+    if (tile) {
+        const int tiles_x = (g.Nx + 61) / 62;
         dim3 gridt((unsigned)tiles_x, (unsigned)tiles_y);
-        if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x, hp);
-        else    hipLaunchKernelGGL((k_cells_tile<T, false, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x, hp);
+        if (nt) hipLaunchKernelGGL((k_cells_tile<T, true, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x);
+        else    hipLaunchKernelGGL((k_cells_tile<T, false, R>), gridt, dim3(64 * R), 0, s, g, o, tiles_x);
     }
     else if (nt) hipLaunchKernelGGL((k_cells<T, true>), grid1, dim3(256), 0, s, g, o);
     else         hipLaunchKernelGGL((k_cells<T, false>), grid1, dim3(256), 0, s, g, o);
     int rc = tpg::launch_status("k_cells");
     if (rc) return rc;
-    if (hp.on) return TPG_OK;                                          // K0 + K1: every halo cell has been written
     // K3 rides in the K2 launch unless the grid is so short that a north-fold source row or the row-Ny
     // substitution could be a continuation row (then K3 must run after K2, as in the reference's order)
     HaloRegions hm = h;

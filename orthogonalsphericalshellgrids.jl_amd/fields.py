@@ -217,6 +217,11 @@ def _agree_across_ranks(arch, value, what):
     group = getattr(arch, "process_group", None)
     if dist.get_world_size(group) != arch.ranks[1]:
         return                                  # not the chain's own group (e.g. one process emulating a band of a longer chain)
+    # Deliberately NOT remembered between calls: any scheme that lets a rank skip the collective on local knowledge (a memo of agreed layouts,
+    # "same as last time") leaves the one rank that brings a different layout alone in it -- the very case this check exists to report
+    # (tests/test_distributed_gloo.py::test_ranks_must_agree_on_the_stage_layout_of_the_pipelined_exchange hangs with such a memo; tried in
+    # round 6).  The cost -- one host-blocking collective per plan build -- is the reason to build a plan ONCE for fields that are filled
+    # every step (halo_fill_plan), which is what a model's time loop does.
     vals = [None] * arch.ranks[1]
     dist.all_gather_object(vals, value, group=group)
     if any(v != vals[0] for v in vals):
@@ -362,24 +367,10 @@ def halo_fill_plan(fields, *, exchange=None, pack_free=False, fields_per_stage=0
     return HaloFillPlan(fields, exchange=exchange, pack_free=pack_free, fields_per_stage=fields_per_stage)
 
 
-_PLANS_PER_FIELD = 8
-
-
 def fill_halo_regions(fields, *, exchange=None):
-    """fill_halo_regions!(fields...) on a tripolar grid.  The HaloFillPlan of a field list is built at its first fill and kept with the
-    list's first field (at most 8 per field; it goes when the field goes): a model fills the same tuples every (sub-)step, and on a
-    distributed grid building a plan costs one host-blocking agreement collective per geometry group -- paid once per field
-    list, not once per fill.  The key holds what a plan depends on -- the fields' identities, their tensors and boundary conditions, the
-    transport override --, so a field whose `data` or conditions were replaced gets a new plan."""
-    fs = [fields] if isinstance(fields, Field) else list(fields)
-    if not fs:
-        return None
-    key = (tuple((id(f), f.data.data_ptr(), id(f.boundary_conditions)) for f in fs), id(exchange), id(_lib.lib()))
-    cache = fs[0].__dict__.setdefault("_fill_plans", {})
-    plan = cache.get(key)
-    if plan is None:
-        plan = HaloFillPlan(fs, exchange=exchange)
-        if len(cache) >= _PLANS_PER_FIELD:
-            cache.pop(next(iter(cache)))
-        cache[key] = plan
-    return plan()
+    """fill_halo_regions!(fields...) on a tripolar grid: builds a HaloFillPlan and runs it once.  For fields that are filled repeatedly
+    (every step of a time loop) build the plan once -- `plan = halo_fill_plan(fields)`, then `plan()`: on a distributed grid every plan BUILD
+    runs one host-blocking agreement collective per geometry group (with the nccl backend it also synchronises the device), a plan CALL
+    runs none.  Plans are not cached behind this function: a plan holds its fields, and a cache reachable from a field ties 32 GB tensors
+    into a reference cycle that only the cycle collector frees (tried in round 6: the next test ran out of HBM)."""
+    return HaloFillPlan(fields, exchange=exchange)()

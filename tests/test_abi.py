@@ -61,7 +61,7 @@ def test_product_library_exports_exactly_the_header(osg):
 
 def test_version_and_status_strings(osg):
     lib = osg._lib.lib()
-    assert lib.tpg_version() == 500
+    assert lib.tpg_version() == 600
     assert b"even" in lib.tpg_status_string(-2)
     assert lib.tpg_status_string(0) == b"ok"
 
@@ -200,3 +200,29 @@ def test_product_library_does_not_know_the_test_double():
     strings = subprocess.run(["strings", prod], capture_output=True, text=True).stdout
     assert "TPG_RCCL_LIBRARY" not in strings and "nccl_shim" not in strings
     assert "TPG_RCCL_LIBRARY" in subprocess.run(["strings", os.path.join(ROOT, "tools", "libtripolar_hip_test.so")], capture_output=True, text=True).stdout
+
+
+def test_cell_kernel_stores_are_all_streaming(tmp_path):
+    """k_cells_tile writes 1 GB at 1/10 degree; every store of it must carry the non-temporal hint, or the arrays stay behind as dirty lines
+    in L2 / Infinity Cache and the NEXT kernel on the stream pays for their eviction (the halo fill of a bench step: 67 instead of 47 us).
+    A first form of round 6's halo-push variant lost the hint on 11 of the 21 stores of the ordinary path without any change to them: the
+    compiler sinks the stores of two branches (edge tile / ordinary tile) into one instruction and keeps a hint only if BOTH had it.  The
+    generated ISA is what counts, so it is checked: the streaming instantiations of both cell kernels have no plain global store."""
+    import subprocess
+    csrc = os.path.join(ROOT, "orthogonalsphericalshellgrids.jl_amd", "csrc")
+    asm = tmp_path / "tpg_grid.s"
+    # compiled as the TEST library compiles it (-DTPG_TEST_ABI): the product's kernel k_cells_tile AND the halo-push variant k_cells_tile_push
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-DTPG_TEST_ABI",
+                        "-S", "--cuda-device-only", "-o", str(asm), os.path.join(csrc, "tpg_grid.hip")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = asm.read_text()
+    found = 0
+    for kernel, nmin in (("12k_cells_tile", 21), ("17k_cells_tile_push", 100)):
+        for T in ("d", "f"):                                           # <double, true, 8>, <float, true, 8>: the streaming instantiations
+            m = re.search(r"^(_ZN12_GLOBAL__N_1%sI%sLb1ELi8E\w*):.*?^\.Lfunc_end" % (kernel, T), text, flags=re.S | re.M)
+            assert m, "%s<%s, true, 8> not found in the ISA" % (kernel, T)
+            stores = [l for l in m.group(0).splitlines() if "global_store" in l]
+            plain = [l.strip() for l in stores if not re.search(r"\bnt\b", l)]
+            assert len(stores) >= nmin and not plain, (kernel, T, len(stores), plain[:5])
+            found += 1
+    assert found == 4

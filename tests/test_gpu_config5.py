@@ -19,6 +19,17 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(autouse=True)
+def _room_for_160_gb():
+    """these tests hold five 32 GB fields: whatever earlier tests left in torch's caching allocator (or in uncollected cycles) goes first"""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    yield
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 SIZE = (8640, 4320, 100)
 HALO = (4, 4, 4)
 SUBSTEPS = 30

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of tpg_build_grid between two settings of TPG_CELLS_VARIANT (test library): 3 = the tile kernel writes the halo cells
-itself (K0 + K1), 2 = tile kernel + the halo pass k_halos (K0 + K1 + K2, the round-5 default).  Geometries: BASELINE config 2 (1/4 degree),
+"""Interleaved A/B of tpg_build_grid between two settings of TPG_CELLS_VARIANT (test library): 2 = tile kernel + the halo pass k_halos
+(K0 + K1 + K2: the product's build), 3 = k_cells_tile_push, the tile kernel writes the halo cells itself (K0 + K1; compiled into the test
+library only: measured in round 6, not adopted -- profiles/r06/build_push_ab.txt).  Geometries: BASELINE config 2 (1/4 degree),
 a 225-row band of config 4 (north, middle, south rank), the 1/10 degree globe.  usage: python tools/build_ab.py [rounds]"""
 import ctypes as C
 import json

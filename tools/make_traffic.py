@@ -21,8 +21,10 @@ def per_kernel(path, counter):
             continue
         m = re.search(r"(k_[a-z_]+)", r["Kernel_Name"])
         name = m.group(1) if m else "?"
-        if name == "k_zipper_cols" and "true>" in r["Kernel_Name"].split("k_zipper_cols")[1][:24]:
-            name = "k_zipper_cols_copy_probe"
+        if name == "k_zipper_cols":                                  # k_zipper_cols<T, W, HY, COPY, GEN>: the copy probe has COPY = true
+            targs = r["Kernel_Name"].split("k_zipper_cols<")[1].split(">")[0].replace(" ", "").split(",")
+            if len(targs) > 3 and targs[3] == "true":
+                name = "k_zipper_cols_copy_probe"
         acc[name].append(float(r["Counter_Value"]))
     return {k: sum(v[1:]) / max(1, len(v[1:])) * 1024.0 for k, v in acc.items()}
 
@@ -30,7 +32,7 @@ def per_kernel(path, counter):
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     sys.path.insert(0, ROOT)
-    from bench import sources_sha16
+    from bench_common import sources_sha16
     csrc = "orthogonalsphericalshellgrids.jl_amd/csrc/"
     grid_src = [csrc + f for f in ("tpg_grid.hip", "tpg_batch.hpp", "tpg_math.hpp")]
     fill_src = [csrc + f for f in ("tpg_zipper_kernels.hpp", "tpg_zipper.hip")]

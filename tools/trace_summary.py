@@ -3,8 +3,8 @@
 to bench STEPS: the plain `--stats` table also averages the auxiliary launches of the same kernels (cold / warm probes, the
 Float32 and config-5 fills), which have other sizes and cache states.  Two launch sequences are recognised by their
 neighbours in the trace:
-  step       k_tables, k_cells_tile, k_fill_merged                      (the timed steps and the instrumented pass)
-  fold pass  k_tables, k_cells_tile, k_zipper_cols, k_periodic_x_vec    (the pass behind `roofline_fold`)
+  step       k_tables, k_cells_tile, k_halos, k_fill_merged                      (the timed steps and the instrumented pass)
+  fold pass  k_tables, k_cells_tile, k_halos, k_zipper_cols, k_periodic_x_vec    (the pass behind `roofline_fold`)
 A `step` whose kernels follow each other within 5 us is a TIMED step (the instrumented pass has stream markers between
 its phases, ~10 us each); only those enter the `timed_step` rows, which are the figures to compare with `roofline`.  Marker-free
 steps that come AFTER the fold pass are the K cold-onset steps of round 5 (`ms_per_step_cold_onset`: started right after 100 passes
@@ -19,9 +19,8 @@ import re
 import statistics
 import sys
 
-# since round 6 tpg_build_grid is k_tables + k_cells_tile (the tile kernel writes the halo cells itself); traces of older builds have k_halos
-STEP = ["k_tables", "k_cells_tile", "k_fill_merged"]
-FOLD = ["k_tables", "k_cells_tile", "k_zipper_cols", "k_periodic_x_vec"]
+STEP = ["k_tables", "k_cells_tile", "k_halos", "k_fill_merged"]
+FOLD = ["k_tables", "k_cells_tile", "k_halos", "k_zipper_cols", "k_periodic_x_vec"]
 
 
 def short(name):
@@ -45,7 +44,7 @@ def main():
            "cold_onset_step": {k: [] for k in STEP}}
     i, seen_fold = 0, False
     while i < len(rows):
-        if names[i:i + len(FOLD)] == FOLD and not is_copy_probe(rows[i + 2]["Kernel_Name"]):
+        if names[i:i + len(FOLD)] == FOLD and not is_copy_probe(rows[i + 3]["Kernel_Name"]):
             for k, d in zip(FOLD, dur[i:i + len(FOLD)]):
                 acc["fold_pass"][k].append(d)
             i += len(FOLD)
