@@ -11,7 +11,7 @@ from .boundary_conditions import (BoundaryCondition, Center, Face, FieldBoundary
                                   apply_y_north_bc, regularize_field_boundary_conditions, sign,
                                   validate_boundary_condition_location, is_zipper)
 from .grids import (CPU, GPU, convert_to_0_360, Distributed, Partition, OrthogonalSphericalShellGrid, R_Earth, Tripolar,
-                    TripolarGrid, is_tripolar, local_row_range, local_sizes, reconstruct_global_grid,
+                    TripolarGrid, is_tripolar, local_row_range, local_sizes, reconstruct_global_grid, share_tables,
                     with_halo, x_domain, y_domain, RightConnected, FullyConnected, Bounded,
                     PeriodicTopology)
 from .fields import (CenterField, Field, HaloFillPlan, XFaceField, YFaceField, ZFaceField, fill_halo_regions,

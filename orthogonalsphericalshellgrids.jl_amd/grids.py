@@ -265,11 +265,28 @@ class TableWorkspace:
         self.key, self.tensor, self.ready, self.stream = key, tensor, None, None
 
 
-# live workspaces by key (weak: a workspace lives exactly as long as a grid that holds it): consecutive band builds of one geometry --
-# every rank's band in an emulated chain, reconstruct_global_grid after a band build, with_halo with a new Hx / Hz -- find the tables of
-# the first one
-_live_workspaces = weakref.WeakValueDictionary()
+# Table reuse is EXPLICIT.  with_halo and reconstruct_global_grid hand the old grid's workspace to the new build (`_tables_from`): that is
+# always on.  Finding the tables of ANY live grid of the same geometry -- consecutive band builds of one geometry in one process (an
+# emulated chain), repeated TripolarGrid() calls -- happens only inside a `share_tables()` scope: outside it a build never depends on which
+# other grids happen to be alive (which path a test exercised used to depend on garbage-collection timing).
+# the live workspaces (weak: a workspace lives exactly as long as a grid that holds it; several of one key may coexist)
+_live_workspaces = weakref.WeakSet()
 _live_lock = threading.Lock()
+_share = threading.local()
+
+
+class share_tables:
+    """with share_tables(): builds in this thread may take the 1-D tables of any live grid of the same geometry (same Nx, Ny, Hy, element
+    type, latitudes, radius, device) instead of recomputing them -- e.g. the bands of an emulated latitude-band chain built one after the
+    other.  Results are identical either way; `grid.tables_reused` says which way a grid was built."""
+
+    def __enter__(self):
+        _share.depth = getattr(_share, "depth", 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        _share.depth -= 1
+        return False
 
 
 def table_key(Nx, Ny, Hy, dtype, southernmost_latitude, north_poles_latitude, radius, device):
@@ -296,9 +313,9 @@ def _build(arch, dtype, size, halo, southernmost_latitude, radius, z, north_pole
         stream = torch.cuda.current_stream(device)
         # tables of the same geometry already in a live workspace?  (the grid we were derived from, else any live grid's)
         ws = tables_from if (tables_from is not None and tables_from.key == key) else None
-        if ws is None:
+        if ws is None and getattr(_share, "depth", 0) > 0:
             with _live_lock:
-                ws = _live_workspaces.get(key)
+                ws = next((w for w in list(_live_workspaces) if w.key == key and w.ready is not None and w.tensor.numel() >= nbytes), None)
         reuse = ws is not None and ws.tensor.numel() >= nbytes and ws.ready is not None
         if reuse:
             p.reserved = _lib.TPG_BUILD_TABLES_VALID
@@ -314,7 +331,7 @@ def _build(arch, dtype, size, halo, southernmost_latitude, radius, z, north_pole
             ws.ready, ws.stream = torch.cuda.Event(), stream.cuda_stream
             ws.ready.record(stream)
             with _live_lock:
-                _live_workspaces[key] = ws
+                _live_workspaces.add(ws)
         Lz, zf, zc = _z_coordinate(z, Nz, Hz, dtype, device)
     ny = jend - jstart + 1
     return OrthogonalSphericalShellGrid(
@@ -338,7 +355,8 @@ def TripolarGrid(arch=None, FT=torch.float64, *, size, southernmost_latitude=-80
     (the reference builds the whole globe on every rank and slices it).
 
     `_tables_from` (not a reference keyword; with_halo / reconstruct_global_grid pass it) names a TableWorkspace whose 1-D tables may be
-    reused if they are of this geometry; without it a live grid of the same geometry is found by key.  Results are identical either way.
+    reused if they are of this geometry; without it the tables are computed -- unless the call sits inside a `share_tables()` scope, where a
+    live grid of the same geometry is found by key.  Results are identical either way.
     """
     arch = GPU() if arch is None else arch
     dtype = _torch_dtype(FT)

@@ -280,6 +280,9 @@ const DTRG = Union{DistributedTripolarGrid, ImmersedBoundaryGrid{<:Any, <:Any, <
 # (same size, new Hx / Hz: src/with_halo.jl:5-44), reconstruct_global_grid after a band build (src/distributed_tripolar_grid.jl:201-226)
 # and consecutive band builds of one geometry find the tables of the first build, and nothing outlives the grids.  A build whose key
 # differs gets a NEW workspace: the tables of a live grid are never overwritten.
+# Reuse is EXPLICIT (as in the Python host, grids.py): with_halo and reconstruct_global_grid hand the old grid's workspace to the new build
+# (`tables_from`), always; finding the tables of ANY live grid of the same geometry happens only inside `share_tables() do ... end`, so that
+# outside it a build never depends on which other grids happen to be alive.
 # The owner array is matched by IDENTITY (===) only: a dictionary keyed by a device array would hash / compare its ELEMENTS
 # (Base.hash(::AbstractArray) indexes them), which a HIPArray refuses (scalar indexing) and any device array makes a PCIe round trip.
 const TPG_BUILD_TABLES_VALID = Int32(1)
@@ -304,6 +307,10 @@ function live_workspace(key, nbytes)
         return nothing
     end
 end
+"`share_tables() do ... end`: builds inside (this task only) may take the 1-D tables of any live grid of the same geometry (e.g. the bands of an emulated chain)"
+share_tables(f) = task_local_storage(f, :tpg_share_tables, true)
+sharing_tables() = get(task_local_storage(), :tpg_share_tables, false)
+
 function keep_workspace!(owner, ws::TableWorkspace)
     lock(STATE_LOCK) do
         push!(prune_workspaces!(GRID_WORKSPACES), WorkspaceOwner(WeakRef(owner), ws))
@@ -322,7 +329,7 @@ end
 
 # ONE tpg_build_grid call fills the 20 padded arrays of the latitude band jstart:jend in HBM (no host passes, no H2D).
 function build_band(arch, FT, size, halo, southernmost_latitude, radius, z, north_poles_latitude, first_pole_longitude,
-                    jstart, jend, LY)
+                    jstart, jend, LY; tables_from = nothing)
     Nλ, Nφ, Nz = size
     Hλ, Hφ, Hz = halo
     isodd(Nλ) && throw(ArgumentError("The number of cells in the longitude dimension should be even!"))   # :81-83
@@ -333,7 +340,9 @@ function build_band(arch, FT, size, halo, southernmost_latitude, radius, z, nort
     nbytes = ccall((:tpg_build_grid_workspace_bytes, libtripolar), Csize_t, (Ref{TpgParams},), p0)
     s   = stream_for(arch)
     key = table_key(arch, FT, Nλ, Nφ, Hφ, southernmost_latitude, north_poles_latitude, radius)
-    ws  = live_workspace(key, nbytes)
+    # the tables of the grid we were derived from (explicit hand-over), else -- inside share_tables() only -- of any live grid of this key
+    ws  = (tables_from !== nothing && tables_from.key == key && sizeof(tables_from.buffer) >= nbytes) ? tables_from :
+          (sharing_tables() ? live_workspace(key, nbytes) : nothing)
     reuse = ws !== nothing
     if reuse
         ws.stream == s || synchronize_stream(ws.stream)          # tables written on another stream: wait for them (a build is a one-off)
@@ -369,9 +378,10 @@ Same keywords, defaults, return type and `ArgumentError` as src/tripolar_grid.jl
 is `HIPGPU()` (the reference's is `CPU()`, which this binding refuses: see `device_array`).
 """
 function TripolarGrid(arch::AbstractArchitecture = HIPGPU(), FT::DataType = Float64; size, southernmost_latitude = -80,
-                      halo = (4, 4, 4), radius = R_Earth, z = (0, 1), north_poles_latitude = 55, first_pole_longitude = 70)
+                      halo = (4, 4, 4), radius = R_Earth, z = (0, 1), north_poles_latitude = 55, first_pole_longitude = 70,
+                      _tables_from = nothing)                      # not a reference keyword: with_halo / reconstruct_global_grid pass the old grid's tables
     return build_band(arch, FT, size, halo, southernmost_latitude, radius, z, north_poles_latitude,
-                      first_pole_longitude, 1, size[2], RightConnected)
+                      first_pole_longitude, 1, size[2], RightConnected; tables_from = _tables_from)
 end
 
 """
@@ -381,7 +391,7 @@ src/distributed_tripolar_grid.jl:24-110: y-partitioning only; the rank's band is
 reference builds the whole globe on every rank's CPU and slices it).
 """
 function TripolarGrid(arch::Distributed, FT::DataType = Float64; halo = (4, 4, 4), size, southernmost_latitude = -80,
-                      radius = R_Earth, z = (0, 1), north_poles_latitude = 55, first_pole_longitude = 70)
+                      radius = R_Earth, z = (0, 1), north_poles_latitude = 55, first_pole_longitude = 70, _tables_from = nothing)
     workers = ranks(arch.partition)
     workers[1] != 1 &&
         throw(ArgumentError("The tripolar grid is supported only on a Y-partitioning configuration"))      # :28-31
@@ -392,21 +402,21 @@ function TripolarGrid(arch::Distributed, FT::DataType = Float64; halo = (4, 4, 4
     jend   = rank == workers[2] - 1 ? size[2] : sum(nlocal[1:rank+1])                                        # :48
     LY     = rank == 0 ? RightConnected : FullyConnected                                                     # :75
     return build_band(arch, FT, size, halo, southernmost_latitude, radius, z, north_poles_latitude,
-                      first_pole_longitude, jstart, jend, LY)
+                      first_pole_longitude, jstart, jend, LY; tables_from = _tables_from)
 end
 
 # src/tripolar_grid_extensions.jl:20-21
 x_domain(grid::TRG) = 0, 360
 y_domain(grid::TRG) = minimum(parent(grid.φᶠᶠᵃ)), 90
 
-# src/with_halo.jl:5-23 (serial) and :25-44 (distributed: `radius` is not forwarded there -- kept).  The constructor finds the old
-# grid's 1-D tables (live_workspace, same key) and builds with TPG_BUILD_TABLES_VALID when only Hx / Hz change; a new Hy changes the key.
+# src/with_halo.jl:5-23 (serial) and :25-44 (distributed: `radius` is not forwarded there -- kept).  The old grid's 1-D tables are handed
+# to the constructor (`_tables_from`), which builds with TPG_BUILD_TABLES_VALID when only Hx / Hz change; a new Hy changes the key.
 function with_halo(new_halo, old_grid::TripolarGrid)
     cm = old_grid.conformal_mapping
     return TripolarGrid(architecture(old_grid), eltype(old_grid); size = (old_grid.Nx, old_grid.Ny, old_grid.Nz),
                         z = cpu_face_constructor_z(old_grid), halo = new_halo, radius = old_grid.radius,
                         north_poles_latitude = cm.north_poles_latitude, first_pole_longitude = cm.first_pole_longitude,
-                        southernmost_latitude = cm.southernmost_latitude)
+                        southernmost_latitude = cm.southernmost_latitude, _tables_from = table_workspace(old_grid))
 end
 
 function with_halo(new_halo, old_grid::DistributedTripolarGrid)
@@ -415,7 +425,7 @@ function with_halo(new_halo, old_grid::DistributedTripolarGrid)
     cm = old_grid.conformal_mapping
     return TripolarGrid(arch, eltype(old_grid); halo = new_halo, size = N, z = cpu_face_constructor_z(old_grid),
                         north_poles_latitude = cm.north_poles_latitude, first_pole_longitude = cm.first_pole_longitude,
-                        southernmost_latitude = cm.southernmost_latitude)
+                        southernmost_latitude = cm.southernmost_latitude, _tables_from = table_workspace(old_grid))
 end
 
 # src/distributed_tripolar_grid.jl:201-226; the band's 1-D tables are the globe's (indexed by global row): the global build reuses them
@@ -425,7 +435,7 @@ function reconstruct_global_grid(grid::DistributedTripolarGrid)
     return TripolarGrid(child_architecture(arch), eltype(grid); halo = halo_size(grid),
                         size = map(sum, concatenate_local_sizes(size(grid), arch)), z = cpu_face_constructor_z(grid),
                         north_poles_latitude = cm.north_poles_latitude, first_pole_longitude = cm.first_pole_longitude,
-                        southernmost_latitude = cm.southernmost_latitude)
+                        southernmost_latitude = cm.southernmost_latitude, _tables_from = table_workspace(grid))
 end
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -2,8 +2,9 @@
 oracle, bit-exact on whole padded arrays.  A small pool of geometries is visited in random order by random operations -- fresh builds, random
 latitude bands, with_halo (new Hx / Hz, sometimes a new Hy), reconstruct_global_grid, builds on a side stream -- while a random subset of the
 grids stays alive, so that table keys repeat, workspaces are shared, dropped and re-created.  Every build is compared with the oracle; every
-build also checks that the flag was set exactly when a live workspace of its key existed.  usage: python tests/soak/soak_tables.py [trials] [seed]"""
-import gc, os, sys
+build also checks that the flag was set exactly when it should be: inside a `share_tables()` scope (half of the trials) when a live workspace
+of its key existed, outside it only for the explicit hand-overs (with_halo of the same key, reconstruct_global_grid).  usage: python tests/soak/soak_tables.py [trials] [seed]"""
+import contextlib, gc, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import orthogonalsphericalshellgrids.jl_amd as osg
@@ -43,10 +44,11 @@ for t in range(trials):
     dtype, tdt = ((np.float64, torch.float64), (np.float32, torch.float32))[int(rng.integers(0, 4)) == 0]
     fpl = float(rng.choice([70.0, 75.0, -12.25]))
     key = grids.table_key(Nx, Ny, halo[1], tdt, kw["southernmost_latitude"], kw["north_poles_latitude"], kw["radius"], torch.device("cuda", 0))
-    expect = any(g.workspace.key == key for g in alive)
+    shared = bool(rng.integers(0, 2))                                    # implicit sharing is explicit since round 6: only inside the scope
+    expect = shared and any(g.workspace.key == key for g in alive)
     op = int(rng.integers(0, 5))
     ctx = torch.cuda.stream(side) if op == 4 else torch.cuda.stream(torch.cuda.current_stream())
-    with ctx:
+    with ctx, (osg.share_tables() if shared else contextlib.nullcontext()):
         if op in (0, 4):                                                # a fresh serial build (op 4: on the side stream)
             g = osg.TripolarGrid(osg.GPU(0), tdt, halo=halo, first_pole_longitude=fpl, **kw)
             check(g, kw, halo, dtype, fpl, "build")

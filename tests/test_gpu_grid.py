@@ -315,21 +315,29 @@ def test_grid_hosts_reuse_the_tables_and_a_changed_key_recomputes(osg, oracle, g
         assert not gk.tables_reused and compare(gk, oracle.build_grid(size, **kw)) == 0, kw
     g32 = osg.TripolarGrid(None, torch.float32, size=size)
     assert not g32.tables_reused
-    gfpl = osg.TripolarGrid(size=size, first_pole_longitude=75)              # first_pole_longitude does not enter the tables
-    assert gfpl.tables_reused and compare(gfpl, oracle.build_grid(size, first_pole_longitude=75)) == 0
-    # consecutive band builds of one geometry, then the globe from the last band
+    # a plain second build of the same geometry does NOT look at which other grids are alive: sharing is explicit
+    again = osg.TripolarGrid(size=size)
+    assert not again.tables_reused and again.workspace is not g.workspace
+    del again
     glob = oracle.build_grid(size)
     bands = []
-    for r in range(3):
-        arch = osg.Distributed(osg.GPU(0), osg.Partition(y=3), local_rank=r)
-        b = osg.TripolarGrid(arch, size=size)
-        assert b.tables_reused and b.workspace is g.workspace                 # g is alive: every band finds its tables
-        j0, j1 = b.jrange
-        for name, ref in glob.items():
-            assert np.array_equal(getattr(b, name).cpu().numpy(), ref[j0 - 1:j1 + 8], equal_nan=True), (r, name)
-        bands.append(b)
-    full = osg.reconstruct_global_grid(bands[-1])
+    with osg.share_tables():                                                  # ... inside this scope any live grid's tables of the key are taken
+        gfpl = osg.TripolarGrid(size=size, first_pole_longitude=75)          # first_pole_longitude does not enter the tables
+        assert gfpl.tables_reused and compare(gfpl, oracle.build_grid(size, first_pole_longitude=75)) == 0
+        # consecutive band builds of one geometry (an emulated chain in one process)
+        for r in range(3):
+            arch = osg.Distributed(osg.GPU(0), osg.Partition(y=3), local_rank=r)
+            b = osg.TripolarGrid(arch, size=size)
+            assert b.tables_reused                                            # a live grid of this geometry exists: every band finds tables
+            j0, j1 = b.jrange
+            for name, ref in glob.items():
+                assert np.array_equal(getattr(b, name).cpu().numpy(), ref[j0 - 1:j1 + 8], equal_nan=True), (r, name)
+            bands.append(b)
+    lone = osg.TripolarGrid(osg.Distributed(osg.GPU(0), osg.Partition(y=3), local_rank=1), size=size)
+    assert not lone.tables_reused                                             # outside the scope: its own tables
+    full = osg.reconstruct_global_grid(bands[-1])                             # explicit hand-over of the band's workspace: always reused
     assert full.tables_reused and compare(full, glob) == 0
+    del lone
     # the flag really skips the kernel: poison the shared tables, a reusing build goes wrong, a build with another key does not
     torch.cuda.synchronize()
     g.workspace.tensor.fill_(0xFF)
@@ -340,7 +348,8 @@ def test_grid_hosts_reuse_the_tables_and_a_changed_key_recomputes(osg, oracle, g
     # a workspace lives as long as a grid holds it: drop them all and the next build computes its own tables again
     del g, g2, bad, bands, b, full, gfpl
     gc.collect()
-    fresh = osg.TripolarGrid(size=size)
+    with osg.share_tables():                                                  # (even where sharing is allowed: nothing of this key is alive)
+        fresh = osg.TripolarGrid(size=size)
     assert not fresh.tables_reused and compare(fresh, glob) == 0
     # the tables may have been written on another stream: the reusing build waits for them
     side = torch.cuda.Stream()

@@ -318,7 +318,11 @@ def test_build_band_sets_the_tables_valid_flag_for_a_live_workspace():
     flag = int(re.search(r"#define TPG_BUILD_TABLES_VALID (\d+)", hdr).group(1))
     assert int(re.search(r"const TPG_BUILD_TABLES_VALID = Int32\((\d+)\)", src).group(1)) == flag
     assert "const GRID_WORKSPACES = WorkspaceOwner[]" in src and "keep_workspace!(arrays[1], ws)" in src
-    assert "reuse ? TPG_BUILD_TABLES_VALID : Int32(0)" in src and "ws  = live_workspace(key, nbytes)" in src
+    assert "reuse ? TPG_BUILD_TABLES_VALID : Int32(0)" in src
+    # reuse is explicit: the old grid's workspace handed over by with_halo / reconstruct_global_grid, or -- inside
+    # share_tables() only -- any live grid's tables of the key
+    assert "(sharing_tables() ? live_workspace(key, nbytes) : nothing)" in src and "tables_from.key == key" in src
+    assert src.count("_tables_from = table_workspace(") == 3 and "share_tables(f) = task_local_storage(f, :tpg_share_tables, true)" in src
     # the key holds exactly what the header says the tables depend on
     key = re.search(r"table_key\(arch, FT, Nλ, Nφ, Hφ, south, npl, radius\) = \((.*)\)", src).group(1)
     for part in ("serial_arch(arch)", "FT", "Int(Nλ)", "Int(Nφ)", "Int(Hφ)", "Float64(south)", "Float64(npl)", "Float64(radius)"):
