@@ -14,8 +14,9 @@ SPECS = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]
 @pytest.mark.parametrize("stage", [0, 1, 3])      # 0: monolithic exchange; k: the pipelined form's stages of k fields (4 fields: 4 / 2 stages)
 @pytest.mark.parametrize("R", [2, 4])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype, stage):
-    size, halo = (48, 40, 3), (4, 4, 2)
+@pytest.mark.parametrize("halo", [(4, 4, 2), (5, 5, 5)], ids=["halo4", "halo5"])      # (5, 5, 5): examples/distributed_bickley_jet.jl:23
+def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype, stage, halo):
+    size = (48, 40, 3)
     (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rng = np.random.default_rng(17)
@@ -89,7 +90,8 @@ def test_pack_unpack_roundtrip_and_layout(osg, gpu):
             assert torch.equal(f, b)
 
 
-def test_config4_eight_bands_at_full_size(osg, gpu, tlib):
+@pytest.mark.parametrize("halo", [(4, 4, 4), (5, 5, 5)], ids=["halo4", "halo5"])      # (5, 5, 5): the halo of the reference's distributed example
+def test_config4_eight_bands_at_full_size(osg, gpu, tlib, halo):
     """BASELINE config 4 at its real geometry: the 1/10 degree grid (3600 x 1800 x 75, halo 4, Float64) as 8 latitude bands of
     ny = 225 rows, the four bench fields c / u / v / zeta, on ONE GPU with the 8 ranks emulated in this process (two-phase
     loop-back transport; the RCCL leg itself is tests/test_gpu_exchange.py).
@@ -100,7 +102,9 @@ def test_config4_eight_bands_at_full_size(osg, gpu, tlib):
         oracle at this size: tests/test_gpu_zipper.py::test_config3_tenth_degree_75_levels).
     Everything is compared on the device: 17 GB of global fields + 17 GB filled copies + 18 GB of slabs."""
     import ctypes as C
-    size, halo, R = (3600, 1800, 75), (4, 4, 4), 8
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    size, R = (3600, 1800, 75), 8
     (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
     lib = osg._lib.lib()
     specs = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]

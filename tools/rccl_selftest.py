@@ -36,7 +36,8 @@ def main():
     for (Nx, Ny, Nz), (Hx, Hy, Hz), nf, dt, tdt in (((48, 40, 3), (4, 4, 2), 3, np.float64, torch.float64),
                                                    ((20, 12, 2), (3, 2, 1), 2, np.float32, torch.float32),
                                                    ((3600, 64, 75), (4, 4, 4), 4, np.float64, torch.float64),
-                                                   ((3600, 225, 75), (4, 4, 4), 4, np.float64, torch.float64)):     # BASELINE config 4's band
+                                                   ((3600, 225, 75), (4, 4, 4), 4, np.float64, torch.float64),      # BASELINE config 4's band
+                                                   ((3600, 225, 75), (5, 5, 5), 4, np.float64, torch.float64)):     # ... at the halo of examples/distributed_bickley_jet.jl:23
         shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
         ft = 1 if dt == np.float64 else 0
         for packed in (True, False):
@@ -78,6 +79,7 @@ def main():
     comm_stream = torch.cuda.Stream(dev)
     for (Nx, Ny, Nz), (Hx, Hy, Hz), nf, dt, tdt in (((48, 40, 3), (4, 4, 2), 5, np.float64, torch.float64),
                                                    ((20, 12, 2), (3, 2, 1), 3, np.float32, torch.float32),
+                                                   ((48, 40, 3), (5, 5, 5), 4, np.float64, torch.float64),
                                                    ((3600, 225, 75), (4, 4, 4), 4, np.float64, torch.float64)):
         shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
         ft = 1 if dt == np.float64 else 0
@@ -139,42 +141,42 @@ def main():
     out["exchange_cost_config4_band_loopback"] = cost
 
     # ---- tpg_fill_halo_regions_distributed_peers: the whole fill of a band in ONE call (zipper / periodic x / seams) ----------
-    (Nx, Ny, Nz), (Hx, Hy, Hz) = (48, 40, 3), (4, 4, 2)
-    shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
-    specs = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]
-    xl = (C.c_int8 * 4)(*[s_[0] for s_ in specs]); yl = (C.c_int8 * 4)(*[s_[1] for s_ in specs]); sg = (C.c_int32 * 4)(*[s_[2] for s_ in specs])
-    nbuf = lib.tpg_y_halo_buffer_elems(4, Nx, Nz, Hx, Hy, Hz)
-    bufs = [torch.empty(nbuf, dtype=torch.float64, device=dev) for _ in range(4)]
-    stream = _lib.current_stream_ptr(dev)
     dcases = []
-    # (a) a middle band: no zipper, both seams (peers = this rank): periodic x, then south halo <- own north interior rows etc.
-    # (b) the north band: zipper + periodic x, then the south seam only (south halo <- own south interior rows: the one send pairs the one recv)
-    for label, south, north, zipper, pipelined in (("middle", 0, 0, 0, False), ("north", 0, -1, 1, False),
-                                                   ("middle", 0, 0, 0, True), ("north", 0, -1, 1, True)):
-        hosts = [rng.uniform(-1, 1, shape) for _ in specs]
-        devs = [torch.from_numpy(h).to(dev) for h in hosts]
-        # expected: the product's own LOCAL fill (bit-exact against the oracle in tests/test_gpu_zipper.py) + the loop-back row moves
-        refs = [d.clone() for d in devs]
-        _lib.check(lib.tpg_fill_halo_regions(_lib.ptr_table(refs), 4, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, zipper, 1, stream))
-        bargs = (bufs[0].data_ptr(), bufs[1].data_ptr() if north >= 0 else None, bufs[2].data_ptr(), bufs[3].data_ptr() if north >= 0 else None)
-        if pipelined:
-            rc = lib.tpg_fill_halo_regions_distributed_pipelined_peers(comm.handle, south, north, zipper, _lib.ptr_table(devs), 4, xl, yl, sg,
-                                                                       *bargs, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream,
-                                                                       C.c_void_p(comm_stream.cuda_stream), 1)
-        else:
-            rc = lib.tpg_fill_halo_regions_distributed_peers(comm.handle, south, north, zipper, _lib.ptr_table(devs), 4, xl, yl, sg,
-                                                             *bargs, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream)
-        torch.cuda.synchronize()
-        good = rc == 0
-        for r, d in zip(refs, devs):
-            want = r.clone()
-            if north >= 0:
-                want[:, :Hy] = r[:, Ny:Ny + Hy]; want[:, Ny + Hy:] = r[:, Hy:2 * Hy]
+    for (Nx, Ny, Nz), (Hx, Hy, Hz) in (((48, 40, 3), (4, 4, 2)), ((48, 40, 3), (5, 5, 5))):        # the second: the distributed example's halo
+        shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
+        specs = [(0, 0, 1), (1, 0, -1), (0, 1, -1), (1, 1, 1)]
+        xl = (C.c_int8 * 4)(*[s_[0] for s_ in specs]); yl = (C.c_int8 * 4)(*[s_[1] for s_ in specs]); sg = (C.c_int32 * 4)(*[s_[2] for s_ in specs])
+        nbuf = lib.tpg_y_halo_buffer_elems(4, Nx, Nz, Hx, Hy, Hz)
+        bufs = [torch.empty(nbuf, dtype=torch.float64, device=dev) for _ in range(4)]
+        stream = _lib.current_stream_ptr(dev)
+        # (a) a middle band: no zipper, both seams (peers = this rank): periodic x, then south halo <- own north interior rows etc.
+        # (b) the north band: zipper + periodic x, then the south seam only (south halo <- own south interior rows: the one send pairs the one recv)
+        for label, south, north, zipper, pipelined in (("middle", 0, 0, 0, False), ("north", 0, -1, 1, False),
+                                                       ("middle", 0, 0, 0, True), ("north", 0, -1, 1, True)):
+            hosts = [rng.uniform(-1, 1, shape) for _ in specs]
+            devs = [torch.from_numpy(h).to(dev) for h in hosts]
+            # expected: the product's own LOCAL fill (bit-exact against the oracle in tests/test_gpu_zipper.py) + the loop-back row moves
+            refs = [d.clone() for d in devs]
+            _lib.check(lib.tpg_fill_halo_regions(_lib.ptr_table(refs), 4, xl, yl, sg, Nx, Ny, Nz, Hx, Hy, Hz, zipper, 1, stream))
+            bargs = (bufs[0].data_ptr(), bufs[1].data_ptr() if north >= 0 else None, bufs[2].data_ptr(), bufs[3].data_ptr() if north >= 0 else None)
+            if pipelined:
+                rc = lib.tpg_fill_halo_regions_distributed_pipelined_peers(comm.handle, south, north, zipper, _lib.ptr_table(devs), 4, xl, yl, sg,
+                                                                           *bargs, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream,
+                                                                           C.c_void_p(comm_stream.cuda_stream), 1)
             else:
-                want[:, :Hy] = r[:, Hy:2 * Hy]
-            good = good and bool(torch.equal(d, want))
-        dcases.append({"band": label, "pipelined": pipelined, "rc": rc, "bit_exact": bool(good)})
-        out["ok"] = out["ok"] and good
+                rc = lib.tpg_fill_halo_regions_distributed_peers(comm.handle, south, north, zipper, _lib.ptr_table(devs), 4, xl, yl, sg,
+                                                                 *bargs, Nx, Ny, Nz, Hx, Hy, Hz, 1, stream)
+            torch.cuda.synchronize()
+            good = rc == 0
+            for r, d in zip(refs, devs):
+                want = r.clone()
+                if north >= 0:
+                    want[:, :Hy] = r[:, Ny:Ny + Hy]; want[:, Ny + Hy:] = r[:, Hy:2 * Hy]
+                else:
+                    want[:, :Hy] = r[:, Hy:2 * Hy]
+                good = good and bool(torch.equal(d, want))
+            dcases.append({"band": label, "halo": [Hx, Hy, Hz], "pipelined": pipelined, "rc": rc, "bit_exact": bool(good)})
+            out["ok"] = out["ok"] and good
     out["distributed_fill"] = dcases
 
     # ---- two exchanges of EQUAL geometry in flight on two streams, each with its own message buffers (seam-buffer ownership) ----
