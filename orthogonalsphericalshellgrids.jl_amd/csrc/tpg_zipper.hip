@@ -242,12 +242,16 @@ static int pack_common(void* const fields[], int nfields, void* buffer, int side
     // 0-based parent row of the slab: pack reads interior rows next to the side, unpack writes halo rows
     int row0 = pack ? (side == 0 ? Hy : Ny) : (side == 0 ? 0 : Ny + Hy);
     const size_t esz = ft == TPG_F64 ? 8 : 4;
-    const int per16 = (int)(16 / esz);
-    bool vec = ((uintptr_t)buffer % 16 == 0) && (g.sx % per16 == 0);
+    // 16-B chunks of the rows when every row start, the message buffer and every field base sit on the 16-B grid (Float64 with aligned
+    // bases: always -- sx is even); otherwise 16-B chunks of the contiguous Hy x sx slabs through element-aligned accesses (k_pack_loose):
+    // Float32 rows with sx = 2 mod 4 -- e.g. Nx = 3600 at the reference's model halo 5 -- or bases off the grid
+    uintptr_t low = (uintptr_t)buffer | (uintptr_t)((size_t)g.sx * esz);
     PtrTable pt;
-    for (int f = 0; f < nfields; ++f) { pt.ptr[f] = fields[f]; vec = vec && ((uintptr_t)fields[f] % 16 == 0); }
-    PackArgs a{ g.sx, g.sy, Nz + 2 * Hz, Hy, row0, g.plane, nfields, vec ? per16 : 1 };
-    long long total = (long long)nfields * a.nlev * Hy * g.sx / a.chunk_elems;
+    for (int f = 0; f < nfields; ++f) { pt.ptr[f] = fields[f]; low |= (uintptr_t)fields[f]; }
+    const bool vec = low % 16 == 0;
+    const int W = (int)(16 / esz);
+    PackArgs a{ g.sx, g.sy, Nz + 2 * Hz, Hy, row0, g.plane, nfields, vec ? W : 1 };
+    long long total = vec ? (long long)nfields * a.nlev * Hy * g.sx / W : (long long)nfields * a.nlev * ((Hy * g.sx + W - 1) / W);
     dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t s = tpg::as_stream(stream);
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -255,11 +259,11 @@ static int pack_common(void* const fields[], int nfields, void* buffer, int side
         if (pack) hipLaunchKernelGGL((k_pack<u32x4, true>), grid, dim3(256), 0, s, pt, static_cast<u32x4*>(buffer), a);
         else      hipLaunchKernelGGL((k_pack<u32x4, false>), grid, dim3(256), 0, s, pt, static_cast<u32x4*>(buffer), a);
     } else if (ft == TPG_F64) {
-        if (pack) hipLaunchKernelGGL((k_pack<double, true>), grid, dim3(256), 0, s, pt, static_cast<double*>(buffer), a);
-        else      hipLaunchKernelGGL((k_pack<double, false>), grid, dim3(256), 0, s, pt, static_cast<double*>(buffer), a);
+        if (pack) hipLaunchKernelGGL((k_pack_loose<double, 2, true>), grid, dim3(256), 0, s, pt, static_cast<double*>(buffer), a);
+        else      hipLaunchKernelGGL((k_pack_loose<double, 2, false>), grid, dim3(256), 0, s, pt, static_cast<double*>(buffer), a);
     } else {
-        if (pack) hipLaunchKernelGGL((k_pack<float, true>), grid, dim3(256), 0, s, pt, static_cast<float*>(buffer), a);
-        else      hipLaunchKernelGGL((k_pack<float, false>), grid, dim3(256), 0, s, pt, static_cast<float*>(buffer), a);
+        if (pack) hipLaunchKernelGGL((k_pack_loose<float, 4, true>), grid, dim3(256), 0, s, pt, static_cast<float*>(buffer), a);
+        else      hipLaunchKernelGGL((k_pack_loose<float, 4, false>), grid, dim3(256), 0, s, pt, static_cast<float*>(buffer), a);
     }
     return tpg::launch_status("k_pack");
 }

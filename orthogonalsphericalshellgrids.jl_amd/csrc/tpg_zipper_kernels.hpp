@@ -572,7 +572,7 @@ struct PackArgs { int sx, sy, nlev, Hy, row0; long long plane; int nfields; int 
 template <typename V, bool PACK>
 __global__ __launch_bounds__(256) void k_pack(PtrTable pt, V* buffer, PackArgs a)
 {
-    // message layout: [field][level][Hy rows][sx]; one item = one V (16 B or one element)
+    // message layout: [field][level][Hy rows][sx]; one item = one V (16 B, 8 B or one element: the widest the rows and bases are aligned to)
     long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per_level = (long long)a.Hy * a.sx / a.chunk_elems;
     const long long per_field = per_level * a.nlev;
@@ -584,6 +584,33 @@ __global__ __launch_bounds__(256) void k_pack(PtrTable pt, V* buffer, PackArgs a
     V* field = static_cast<V*>(pt.ptr[f]) + ((long long)a.plane * lev + (long long)a.sx * a.row0) / a.chunk_elems + w;
     if (PACK) buffer[item] = *field;
     else *field = buffer[item];
+}
+
+// Float32 rows whose length is no multiple of 16 B (sx = 2 mod 4: Nx = 3600 at the reference's model halo 5), or bases off the 16-B
+// grid: the Hy x sx slab of one (field, level) is ONE contiguous run on both sides, so it moves as 16-B chunks counted from the slab's
+// first element through element-aligned accesses (free on this device, see GEN above); the last chunk of a slab may be short.
+template <typename T, int W, bool PACK>
+__global__ __launch_bounds__(256) void k_pack_loose(PtrTable pt, T* buffer, PackArgs a)
+{
+    typedef typename Vec<T, W>::loose_t lvec_t;
+    long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int slab = a.Hy * a.sx;
+    const int cps = (slab + W - 1) / W;                           // chunks per slab
+    const long long per_field = (long long)cps * a.nlev;
+    if (item >= per_field * a.nfields) return;
+    const int f = (int)(item / per_field);
+    const long long r = item - (long long)f * per_field;
+    const int lev = (int)(r / cps);
+    const int e0 = ((int)(r - (long long)lev * cps)) * W;         // first element of the chunk inside the slab
+    T* field = static_cast<T*>(pt.ptr[f]) + a.plane * lev + (long long)a.sx * a.row0 + e0;
+    T* msg = buffer + ((long long)f * a.nlev + lev) * slab + e0;
+    T* dst = PACK ? msg : field;
+    const T* src = PACK ? field : msg;
+    if (e0 + W <= slab) {
+        *reinterpret_cast<lvec_t*>(dst) = *reinterpret_cast<const lvec_t*>(src);
+    } else {
+        for (int v = 0; v < slab - e0; ++v) dst[v] = src[v];
+    }
 }
 
 int check_fields(void* const fields[], int nfields)

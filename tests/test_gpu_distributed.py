@@ -62,26 +62,35 @@ def test_band_halo_fill_with_loopback_transport(osg, oracle, gpu, R, dtype, stag
             assert np.array_equal(f.data.cpu().numpy(), g[:, jstart - 1:jend + 2 * Hy]), (r, f.loc)
 
 
-def test_pack_unpack_roundtrip_and_layout(osg, gpu):
-    """message layout [field][level][Hy][sx]; pack reads interior rows, unpack writes halo rows"""
+@pytest.mark.parametrize("tdt,size,halo,offset", [
+    (torch.float64, (20, 12, 2), (4, 3, 1), 0),          # 16-B chunks
+    (torch.float64, (20, 12, 2), (5, 5, 5), 0),          # the reference's model halo: Float64 rows stay 16-B rows
+    (torch.float64, (20, 12, 2), (5, 3, 1), 1),          # field bases 8 B off the 16-B grid: element-aligned 16-B chunks of the slabs (k_pack_loose)
+    (torch.float32, (20, 12, 2), (4, 3, 1), 0),          # sx = 28: 16-B chunks
+    (torch.float32, (20, 12, 2), (5, 5, 5), 0),          # sx = 30 = 2 mod 4 (as Nx = 3600 at halo 5): k_pack_loose, a short last chunk per slab
+    (torch.float32, (20, 12, 2), (5, 3, 1), 1),          # bases 4 B off: k_pack_loose
+])
+def test_pack_unpack_roundtrip_and_layout(osg, gpu, tdt, size, halo, offset):
+    """message layout [field][level][Hy][sx]; pack reads interior rows, unpack writes halo rows -- on the 16-B grid (k_pack) and off it (k_pack_loose)"""
     lib = osg._lib.lib()
-    size, halo = (20, 12, 2), (4, 3, 1)
     (Nx, Ny, Nz), (Hx, Hy, Hz) = size, halo
     shape = (Nz + 2 * Hz, Ny + 2 * Hy, Nx + 2 * Hx)
-    fs = [torch.rand(shape, dtype=torch.float64, device=gpu) for _ in range(3)]
+    ft = osg._lib.ft_of(tdt)
+    count = shape[0] * shape[1] * shape[2]
+    fs = [torch.rand(count + offset, dtype=tdt, device=gpu)[offset:].view(shape) for _ in range(3)]
     ptrs = osg._lib.ptr_table(fs)
     n = lib.tpg_y_halo_buffer_elems(3, Nx, Nz, Hx, Hy, Hz)
     assert n == 3 * (Nx + 2 * Hx) * Hy * (Nz + 2 * Hz)
     for side, rows in ((0, slice(Hy, 2 * Hy)), (1, slice(Ny, Ny + Hy))):
-        buf = torch.empty(n, dtype=torch.float64, device=gpu)
-        assert lib.tpg_pack_y_halo(ptrs, 3, buf.data_ptr(), side, *size, *halo, 1, None) == 0
+        buf = torch.empty(n, dtype=tdt, device=gpu)
+        assert lib.tpg_pack_y_halo(ptrs, 3, buf.data_ptr(), side, *size, *halo, ft, None) == 0
         torch.cuda.synchronize()
         want = torch.stack([f[:, rows] for f in fs]).flatten()
         assert torch.equal(buf, want)
     for side, rows in ((0, slice(0, Hy)), (1, slice(Ny + Hy, Ny + 2 * Hy))):
-        buf = torch.rand(n, dtype=torch.float64, device=gpu)
+        buf = torch.rand(n, dtype=tdt, device=gpu)
         before = [f.clone() for f in fs]
-        assert lib.tpg_unpack_y_halo(ptrs, 3, buf.data_ptr(), side, *size, *halo, 1, None) == 0
+        assert lib.tpg_unpack_y_halo(ptrs, 3, buf.data_ptr(), side, *size, *halo, ft, None) == 0
         torch.cuda.synchronize()
         msg = buf.view(3, Nz + 2 * Hz, Hy, Nx + 2 * Hx)
         for f, b, m in zip(fs, before, msg):
