@@ -8,7 +8,7 @@
 #     python tests/compare_reference_dump.py <outdir>            # on a box with the built library (MI355X); without a GPU: its CPU-only switch
 #
 # NOT exercised in the build container (no Julia).  It only calls the package's EXPORTED API -- TripolarGrid (src/tripolar_grid.jl:59),
-# CenterField / XFaceField / YFaceField, set!, fill_halo_regions! -- exactly as the package's own tests do
+# Field{LX, LY, LZ}(grid), set!, fill_halo_regions! -- exactly as the package's own tests do
 # (test/test_zipper_boundary_conditions.jl:5-31, test/runtests.jl:8-41); no file of the reference is copied.
 #
 # Format "tripolar-reference-dump-1" (tests/compare_reference_dump.py writes the same format from an .npz for its self-test):
@@ -20,10 +20,27 @@
 # Grid arrays are dumped by FIELD NAME of the OrthogonalSphericalShellGrid struct (getproperty(grid, :Δyᶠᶜᵃ) -> "dy_fc"), not by the
 # position they had in the constructor call: src/tripolar_grid.jl:321-324 passes Δy as (cc, cf, fc, ff), and whether Oceananigans'
 # positional parameters are named in that order is exactly one of the things the comparison settles.
-using OrthogonalSphericalShellGrids
+#
+# SECOND MODE, `--glue`: the same cases through THIS repository's Julia binding instead of the reference package --
+#
+#     julia --project=<environment with Oceananigans> dump_reference.jl --glue <outdir>      # on an MI355X host, LIBTRIPOLAR_HIP set
+#     python tests/compare_reference_dump.py <outdir>                                        # expects every array BIT-identical
+#
+# -- i.e. the first execution of julia/TripolarHIP.jl: TripolarGrid(HIPGPU(), FT; ...), the Field constructors and the intercepted
+# fill_halo_regions!.  What the library computes is already checked through Python; this checks what the glue adds (argument marshalling,
+# array order and layout, the field-location / sign policy, the fill interception): the comparator demands 0 differing elements.
 using Oceananigans
 using Oceananigans.BoundaryConditions: fill_halo_regions!
 using Oceananigans.Grids: halo_size
+
+const GLUE = "--glue" in ARGS
+if GLUE
+    include(joinpath(@__DIR__, "TripolarHIP.jl"))
+    using .TripolarHIP
+else
+    using OrthogonalSphericalShellGrids
+end
+dump_arch() = GLUE ? HIPGPU() : CPU()
 
 const GRID_ARRAYS = (
     "lambda_cc" => :λᶜᶜᵃ, "lambda_fc" => :λᶠᶜᵃ, "lambda_cf" => :λᶜᶠᵃ, "lambda_ff" => :λᶠᶠᵃ,
@@ -66,7 +83,7 @@ end
 function dump_grid(outdir, case)
     dir = joinpath(outdir, case.name)
     mkpath(dir)
-    grid = TripolarGrid(CPU(), case.FT; case.kwargs...)
+    grid = TripolarGrid(dump_arch(), case.FT; case.kwargs...)
     arrays = Dict{String, Any}()
     for (name, sym) in GRID_ARRAYS
         arrays[name] = dump_array(dir, name, getproperty(grid, sym))
@@ -83,19 +100,31 @@ function dump_fields(outdir, halo)
     name = "fields_10x10_halo$(halo[1])"
     dir = joinpath(outdir, name)
     mkpath(dir)
-    grid = TripolarGrid(CPU(); size = (10, 10, 1), halo)
+    grid = TripolarGrid(dump_arch(); size = (10, 10, 1), halo)
     fields = Dict{String, Any}()
     loc(f) = collect(String(nameof(L)) for L in Oceananigans.Fields.location(f))
-    for (fname, ctor, init, what) in (("c_one", CenterField, 1, "set!(c, 1)"), ("u_one", XFaceField, 1, "set!(u, 1)"), ("v_one", YFaceField, 1, "set!(v, 1)"),
-                                      ("c_x", CenterField, (x, y, z) -> x, "set!(c, (x, y, z) -> x)"), ("u_x", XFaceField, (x, y, z) -> x, "set!(u, (x, y, z) -> x)"),
-                                      ("v_x", YFaceField, (x, y, z) -> x, "set!(v, (x, y, z) -> x)"))
-        f = ctor(grid)
-        set!(f, init)
+    # glue mode: HIPGPU() has no Oceananigans kernels, so `set!` cannot run there; the pre-fill state is written into the parent array
+    # directly (reproducible values everywhere, halos included -- the fill must overwrite them) and the comparator fills the same state
+    function initialise!(f, init, k)
+        GLUE || return set!(f, init)
+        p = parent(f.data)
+        copyto!(p, reshape([sin(0.37 * (n + 1000k)) for n in 1:length(p)], size(p)))
+        return f
+    end
+    # glue mode builds z-reduced fields (the reduced-field case of test/test_zipper_boundary_conditions.jl:47-54): a default 3-D field carries
+    # Oceananigans' no-flux bottom / top conditions, whose halo kernels HIPGPU() cannot launch (the binding says so with an ArgumentError)
+    make_field(LX, LY) = GLUE ? Field{LX, LY, Nothing}(grid) : Field{LX, LY, Center}(grid)
+    for (k, (fname, LX, LY, init, what)) in enumerate((("c_one", Center, Center, 1, "set!(c, 1)"), ("u_one", Face, Center, 1, "set!(u, 1)"),
+                                                       ("v_one", Center, Face, 1, "set!(v, 1)"), ("c_x", Center, Center, (x, y, z) -> x, "set!(c, (x, y, z) -> x)"),
+                                                       ("u_x", Face, Center, (x, y, z) -> x, "set!(u, (x, y, z) -> x)"),
+                                                       ("v_x", Center, Face, (x, y, z) -> x, "set!(v, (x, y, z) -> x)")))
+        f = make_field(LX, LY)
+        initialise!(f, init, k)
         before = dump_array(dir, fname * "_before", f.data)
         fill_halo_regions!(f)
         after = dump_array(dir, fname, f.data)
         fields[fname] = (file = after.file, before = before.file, dims = after.dims, eltype = after.eltype, location = loc(f),
-                         sign = Int(f.boundary_conditions.north.condition), initial = what)
+                         sign = Int(f.boundary_conditions.north.condition), initial = GLUE ? "sin(0.37 (n + 1000 k)) over the whole parent" : what)
     end
     kw = (size = collect(size(grid)), halo = collect(halo_size(grid)), north_poles_latitude = 55.0, first_pole_longitude = 70.0,
           southernmost_latitude = -80.0, radius = Float64(grid.radius))
@@ -112,7 +141,8 @@ function main(outdir)
     for halo in ((4, 4, 4), (5, 5, 5))
         push!(cases, dump_fields(outdir, halo))
     end
-    generator = "julia $(VERSION), OrthogonalSphericalShellGrids $(pkgversion(OrthogonalSphericalShellGrids)), Oceananigans $(pkgversion(Oceananigans))"
+    generator = GLUE ? "glue: julia $(VERSION), TripolarHIP.jl over $(TripolarHIP.libtripolar), Oceananigans $(pkgversion(Oceananigans))" :
+                       "julia $(VERSION), OrthogonalSphericalShellGrids $(pkgversion(OrthogonalSphericalShellGrids)), Oceananigans $(pkgversion(Oceananigans))"
     open(joinpath(outdir, "manifest.json"), "w") do io
         print(io, "{\"format\": \"tripolar-reference-dump-1\", \"endianness\": \"little\", \"generator\": ", json_str(generator), ", \"cases\": [\n")
         print(io, join((json(c) for c in cases), ",\n"))
@@ -121,4 +151,6 @@ function main(outdir)
     println("wrote ", joinpath(outdir, "manifest.json"))
 end
 
-main(length(ARGS) >= 1 ? ARGS[1] : "reference_dump")
+let dirs = filter(a -> !startswith(a, "--"), ARGS)
+    main(isempty(dirs) ? (GLUE ? "glue_dump" : "reference_dump") : dirs[1])
+end

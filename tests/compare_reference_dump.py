@@ -17,6 +17,8 @@ What is compared, per grid case (TripolarGrid(CPU(), FT; kwargs...) of the refer
 and per field case (test/test_zipper_boundary_conditions.jl:5-31,56-63): the reference's filled parent array against our
 fill_halo_regions! of the reference's own pre-fill array, BIT-EXACT.
 Every mismatch names the "[recalled]" reading of SURVEY.md Appendix A it implicates.  Exit status 0 = everything within tolerance.
+A dump whose generator starts with "glue" (julia/dump_reference.jl --glue: the same cases through julia/TripolarHIP.jl on an MI355X, the first
+execution of that binding) was computed by THIS library: there every array must be bit-identical, and a difference implicates the binding.
 No file of the reference is read or copied here: a dump is data (arrays the reference computed)."""
 import argparse
 import json
@@ -53,6 +55,9 @@ IMPLICATES = {
     ("dy_order",): "src/tripolar_grid.jl:321-324 passes Dy as (cc, cf, fc, ff): if the dump's Dy_fc equals OUR Dy_cf, Oceananigans' positional "
                    "parameters are (cc, fc, cf, ff) and the grid's field NAMES are swapped relative to the arrays' content (enum tpg_array "
                    "follows the call's position, include/tripolar_hip.h:62-69)",
+    ("glue",): "a dump made through julia/TripolarHIP.jl must be BIT-identical to the same library driven from Python: a difference is the "
+               "binding's marshalling -- the TpgParams layout / keyword forwarding (build_band), the order of the 20 output pointers against "
+               "enum tpg_array, the OffsetArray offsets, or the device-to-host copy of HIPArray",
     ("field",): "zipper index / sign map (zipper_boundary_condition.jl:70-155), fill order zipper -> periodic x, the sign policy of "
                 "tripolar_grid_extensions.jl:49-53 -- all pinned by the reference's own tests: a mismatch here is a bug, not a reading",
 }
@@ -174,10 +179,11 @@ def _max_abs_deg(got, ref, wrap):
     if wrap:
         d = np.minimum(d, np.abs(360.0 - d))
     d[np.isnan(d)] = np.inf
-    return (float(d.max()) if d.size else 0.0), int((got != ref).sum())
+    return (float(d.max()) if d.size else 0.0), int((~((got == ref) | (np.isnan(got) & np.isnan(ref)))).sum())
 
 
-def compare_grid(case, case_dir, side):
+def compare_grid(case, case_dir, side, exact=False):
+    """exact: the dump was made by THIS library through another binding (julia/dump_reference.jl --glue): 0 differing elements or a finding"""
     kw, et = case["kwargs"], case["eltype"]
     Hy = int(kw["halo"][1])
     ours = side.grid(kw, et)
@@ -231,6 +237,11 @@ def compare_grid(case, case_dir, side):
         if n in ref:
             a, b = float(ours[n][Hy + 1:].astype(np.float64).sum()), float(ref[n][Hy + 1:].astype(np.float64).sum())
             sums[n] = {"ours": a, "reference": b, "rel": abs(a - b) / abs(b) if b else 0.0}
+    if exact:
+        for r in rows:
+            r["ok"] = r["differing"] == 0
+            if not r["ok"]:
+                findings.append({"array": r["array"], "region": r["region"], "differing": r["differing"], "implicates": IMPLICATES[("glue",)]})
     return {"case": case["name"], "side": side.name, "eltype": et, "kwargs": kw, "arrays": rows, "dy_order": dy_order, "area_sums_rows_ge_2": sums,
             "findings": findings, "ok": all(r["ok"] for r in rows) and not findings}
 
@@ -262,20 +273,24 @@ def compare_fields(case, case_dir, side):
 
 def compare_dump(dump_dir, sides):
     man = read_dump(dump_dir)
+    exact = str(man.get("generator", "")).startswith("glue")          # julia/dump_reference.jl --glue: this library through the Julia binding
     reports = []
     for case in man["cases"]:
         cdir = os.path.join(dump_dir, case["name"])
         for side in sides:
             if case.get("arrays"):
-                reports.append(compare_grid(case, cdir, side))
+                reports.append(compare_grid(case, cdir, side, exact))
             if case.get("fields"):
                 reports.append(compare_fields(case, cdir, side))
-    return {"dump": os.path.abspath(dump_dir), "generator": man.get("generator"), "metric_rtol": METRIC_RTOL, "coord_atol_deg": COORD_ATOL_DEG,
+    return {"dump": os.path.abspath(dump_dir), "generator": man.get("generator"), "bit_exact_required": exact,
+            "metric_rtol": METRIC_RTOL, "coord_atol_deg": COORD_ATOL_DEG,
             "reports": reports, "ok": all(r["ok"] for r in reports)}
 
 
 def print_report(rep, out=sys.stdout):
     print(f"dump: {rep['dump']}  (generator: {rep['generator']})", file=out)
+    if rep.get("bit_exact_required"):
+        print("a dump of THIS library through the Julia binding: every array must be bit-identical", file=out)
     for r in rep["reports"]:
         print(f"\n== {r['case']}  vs {r['side']}: {'OK' if r['ok'] else 'MISMATCH'}", file=out)
         for a in r.get("arrays", []):

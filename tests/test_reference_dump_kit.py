@@ -97,18 +97,45 @@ def test_dump_script_calls_only_the_exported_api_and_writes_this_format():
     """static (no Julia here): the script runs the reference package itself, names every one of the 20 struct fields, the reference's own test
     grids and the model halo (5, 5, 5), writes the format the comparator reads, and copies nothing from the reference's files"""
     src = open(JL).read()
-    assert "using OrthogonalSphericalShellGrids" in src and "TripolarGrid(CPU(), case.FT; case.kwargs...)" in src and "fill_halo_regions!(f)" in src
+    assert "using OrthogonalSphericalShellGrids" in src and "TripolarGrid(dump_arch(), case.FT; case.kwargs...)" in src and "fill_halo_regions!(f)" in src
+    assert "dump_arch() = GLUE ? HIPGPU() : CPU()" in src
     assert '"format\\": \\"tripolar-reference-dump-1\\"' in src and "htol.(p)" in src and "parent(a)" in src
     names = re.findall(r'"([a-z]+_[cf][cf])" => :', src)
     assert sorted(names) == sorted(crd.ARRAY_NAMES)
     for needle in ("size = (4, 5, 1), first_pole_longitude = 75, north_poles_latitude = 35", "size = (10, 10, 1)", "size = (60, 30, 1)",
-                   "size = (360, 180, 1)", "halo = (5, 5, 5)", "CenterField", "XFaceField", "YFaceField"):
+                   "size = (360, 180, 1)", "halo = (5, 5, 5)", "Field{LX, LY, Center}(grid)", '("u_one", Face, Center, 1', '("v_one", Center, Face, 1'):
         assert needle in src, needle
     code = re.sub(r"#.*", "", src)
-    assert "include(" not in code and "@testset" not in code and "ccall" not in code          # the package's API only; no test file pulled in
+    # the package's API only, no test file pulled in; the one include is this repository's own binding, in --glue mode
+    assert re.findall(r"include\(([^\n]*)\)", code) == ['joinpath(@__DIR__, "TripolarHIP.jl")'] and "@testset" not in code and "ccall" not in code
+    # --glue: the same cases through julia/TripolarHIP.jl on HIPGPU(); reduced fields (no bottom / top condition), pre-fill state written
+    # into the parent, a generator string the comparator recognises (bit-exact mode)
+    assert 'const GLUE = "--glue" in ARGS' in src and "Field{LX, LY, Nothing}(grid)" in src and 'GLUE ? "glue: julia' in src
+    assert "GLUE || return set!(f, init)" in src
     # blocks balance (as for the glue: a coarse syntax check)
     openers = len(re.findall(r"(?m)^\s*(?:function|for|if|let|begin)\b(?!.*\bend\s*$)", code)) + len(re.findall(r"\bdo\s*(?:\w+\s*)?$", code, flags=re.M))
     assert openers == len(re.findall(r"(?m)^\s*end\b", code)), openers
+
+
+def test_a_glue_dump_must_be_bit_identical(oracle, tmp_path):
+    """A dump whose generator starts with "glue" was computed by this library through the Julia binding: the comparator then demands 0
+    differing elements (a one-ulp difference, fine against the reference, is a finding that names the binding) -- and passes an exact dump."""
+    cases = _cases(oracle)
+    d = str(tmp_path / "exact")
+    crd.write_dump(d, cases, "glue: self-test")
+    rep = crd.compare_dump(d, [crd.OracleSide()])
+    assert rep["bit_exact_required"] and rep["ok"], json.dumps([r for r in rep["reports"] if not r["ok"]])[:2000]
+    g = cases[0]
+    g["arrays"] = {n: a.copy() for n, a in g["arrays"].items()}
+    g["arrays"]["dx_cc"][20, 30] = np.nextafter(g["arrays"]["dx_cc"][20, 30], np.inf)       # one ulp: within 1e-12, not bit-identical
+    d2 = str(tmp_path / "one_ulp")
+    crd.write_dump(d2, cases, "glue: self-test with one ulp planted")
+    rep = crd.compare_dump(d2, [crd.OracleSide()])
+    assert not rep["ok"]
+    bad = [f for r in rep["reports"] for f in r["findings"]]
+    assert len(bad) == 1 and bad[0]["array"] == "dx_cc" and bad[0]["differing"] == 1 and "marshalling" in bad[0]["implicates"]
+    crd.write_dump(d2, cases, "julia 1.10, OrthogonalSphericalShellGrids 0.2.1")             # the same arrays as a REFERENCE dump: within tolerance
+    assert crd.compare_dump(d2, [crd.OracleSide()])["ok"]
 
 
 @pytest.mark.gpu
