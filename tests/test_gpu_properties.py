@@ -12,6 +12,10 @@ permutation copy of interior cells into halo cells (src/zipper_boundary_conditio
                   left bit-identical, on the whole parent, by the fill kernels applied to them as fields of their location with sign +1:
                   two kernel families with separately written index maps agreeing on every halo cell.
 
+  * halo window   what a logical cell (i, j) of a grid array holds does not depend on the halo width: the (4, 4, 4) grid is, bit for bit, the
+                  inner window of the (5, 5, 5) grid, and the (2, 3, 1) grid the inner window of that -- interior, fold rows, periodic
+                  columns and the continuation rows alike (three launches with three table layouts and three tile grids).
+
 The kernels under test are the ones the bench step and config 5 launch (k_fill_merged, plain and GEN); parity against the oracle at these
 sizes is tests/test_gpu_zipper.py / test_gpu_config5.py -- this file is the independent cross-check that needs no second implementation."""
 import ctypes as C
@@ -130,3 +134,15 @@ def test_a_built_grid_is_a_fixed_point_of_the_halo_fill(osg, gpu, size, halo, td
         torch.cuda.synchronize()
         same = (b[0] == a) | (torch.isnan(b[0]) & torch.isnan(a))
         assert bool(same.all()), (name, int((~same).sum()))
+
+
+@pytest.mark.parametrize("tdt", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_grid_values_do_not_depend_on_the_halo_width(osg, gpu, tdt):
+    size = (3600, 1800, 1)
+    wide, mid, narrow = (osg.TripolarGrid(None, tdt, size=size, halo=h) for h in ((5, 5, 5), (4, 4, 4), (2, 3, 1)))
+    for name in osg._lib.ARRAY_NAMES:
+        a5, a4, a2 = getattr(wide, name), getattr(mid, name), getattr(narrow, name)
+        for outer, inner, dy, dx in ((a5, a4, 1, 1), (a4, a2, 1, 2)):
+            w = outer[dy:outer.shape[0] - dy, dx:outer.shape[1] - dx]
+            same = (w == inner) | (torch.isnan(w) & torch.isnan(inner))
+            assert w.shape == inner.shape and bool(same.all()), (name, int((~same).sum()))
