@@ -146,3 +146,19 @@ def test_grid_values_do_not_depend_on_the_halo_width(osg, gpu, tdt):
             w = outer[dy:outer.shape[0] - dy, dx:outer.shape[1] - dx]
             same = (w == inner) | (torch.isnan(w) & torch.isnan(inner))
             assert w.shape == inner.shape and bool(same.all()), (name, int((~same).sum()))
+
+
+@pytest.mark.parametrize("size,halo", [((3600, 1800, 1), (4, 4, 4)), ((8640, 4320, 1), (5, 5, 5))], ids=["tenth", "twentyfourth-halo5"])
+def test_face_areas_are_the_products_of_their_edge_lengths(osg, gpu, size, halo):
+    """src/tripolar_grid_utils.jl:34-35: Az_fc = Dy_fc * Dx_fc and Az_cf = Dy_cf * Dx_cf -- one Float64 multiply, so the stored arrays must
+    satisfy it exactly on every row the metric kernel owns (j >= 2; rows j <= 1 are the lat-lon continuation, src/tripolar_grid.jl:277-300)
+    and, the halo fills being copies with sign +1 through one index map, on the north fold rows and the periodic columns as well.  It also
+    pins WHICH Dy array sits under which name: with Dy_fc and Dy_cf swapped (the positional-order question of src/tripolar_grid.jl:321-324)
+    the identity fails."""
+    gc.collect(); torch.cuda.empty_cache()
+    g = osg.TripolarGrid(size=size, halo=halo)
+    Hy = halo[1]
+    rows = slice(Hy + 1, None)
+    assert torch.equal(g.az_fc[rows], g.dy_fc[rows] * g.dx_fc[rows])
+    assert torch.equal(g.az_cf[rows], g.dy_cf[rows] * g.dx_cf[rows])
+    assert not torch.equal(g.az_fc[rows], g.dy_cf[rows] * g.dx_fc[rows])
