@@ -74,7 +74,8 @@ def test_bench_prints_one_contract_line(gpu):
     # config 5: the fills of one baroclinic step at 1/24 degree x 100 levels
     fs = d["fill_step"]
     assert "skipped" in fs or (fs["fill3d_us"] > 0 and fs["substep_fills_us"] > 0 and fs["substeps"] == 30
-                               and abs(fs["total_us"] - fs["fill3d_us"] - fs["substep_fills_us"]) < 1e-6 and fs["fields_GB"] > 160)
+                               and abs(fs["total_us"] - fs["fill3d_us"] - fs["substep_fills_us"]) < 1e-6 and fs["fields_GB"] > 160
+                               and 0.5 * fs["fill3d_us"] < fs["fill3d_cold_us"] < 1.5 * fs["fill3d_us"])
     # the same fills at the reference's own model halo (5, 5, 5) (examples/bickley_jet.jl:21), halo 4 by the same method beside them:
     # ONE launch per fill at the odd Hx too (the first kernel's duration is the whole call's, minus the event bracket's overhead)
     h5 = d["fill_step_halo5"]
