@@ -124,6 +124,62 @@ def test_struct_layout_matches_tpg_params():
     assert fields == cfields, (fields, cfields)
 
 
+def _call_arguments(src, start):
+    """the top-level comma-separated arguments of the call whose opening parenthesis is at src[start]"""
+    depth, args, cur = 0, [], ""
+    for ch in src[start:]:
+        if ch in "([{":
+            depth += 1
+            if depth == 1:
+                continue
+        elif ch in ")]}":
+            depth -= 1
+            if depth == 0:
+                args.append(cur.strip())
+                return args
+        if ch == "," and depth == 1:
+            args.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    raise AssertionError("unbalanced call")
+
+
+def test_every_tpg_params_constructor_call_is_positionally_right():
+    """Julia's default struct constructor is positional: every `TpgParams(...)` in the glue must pass one value per field of the struct, the
+    geometry and mapping parameters in the header's order (a swapped pair of Float64 latitudes would compile and build a wrong grid)."""
+    src = open(JL).read()
+    body = src[src.index("struct TpgParams"):src.index("\nend", src.index("struct TpgParams"))]
+    nfields = len(re.findall(r"(\w+)::(Int32|Float64)", body))
+    calls = [m.end() - 1 for m in re.finditer(r"(?<!struct )\bTpgParams\(", src)]
+    assert len(calls) >= 2
+    want = ["Nλ", "Nφ", "Nz", "Hλ", "Hφ", "Hz", "southernmost_latitude", "north_poles_latitude", "first_pole_longitude", "radius", "ft_code(FT)",
+            "jstart", "jend"]
+    for c in calls:
+        args = _call_arguments(src, c)
+        assert len(args) == nfields == 14, (len(args), args)
+        assert args[:13] == want, args
+        assert args[13] in ("0", "reuse ? TPG_BUILD_TABLES_VALID : Int32(0)"), args[13]
+
+
+def test_the_twenty_arrays_are_taken_in_the_order_of_enum_tpg_array():
+    """build_band hands tpg_build_grid 20 pointers and names them by POSITION: the destructuring order must be enum tpg_array's (header), and
+    the grid constructor must receive them in that same order with z between the coordinates and the metrics (src/tripolar_grid.jl:304-330)."""
+    src = open(JL).read()
+    hdr = open(os.path.join(ROOT, "include", "tripolar_hip.h")).read()
+    enum = hdr[hdr.index("enum tpg_array {"):hdr.index("TPG_NUM_ARRAYS")]
+    names = re.findall(r"TPG_(LAMBDA|PHI|DX|DY|AZ)_([CF][CF])", enum)
+    assert len(names) == 20
+    greek = {"LAMBDA": "λ", "PHI": "φ", "DX": "Δx", "DY": "Δy", "AZ": "Az"}
+    want = [greek[k] + loc.lower() for k, loc in names]
+    lhs = src[src.index("λcc, λfc"):src.index("= off.(arrays)")]
+    got = [t.strip() for t in lhs.replace("\n", " ").split(",") if t.strip()]
+    assert got == want, (got, want)
+    ctor = src[src.index("return OrthogonalSphericalShellGrid{Periodic, LY, Bounded}("):]
+    args = _call_arguments(ctor, ctor.index("("))
+    assert args[8:16] == want[:8] and args[16] == "on_architecture(arch, zc)" and args[17:29] == want[8:], args
+    assert "arrays = [device_array(arch, FT, Nλ + 2Hλ, ny + 2Hφ) for _ in 1:20]" in src and "ptrs = Ptr{Cvoid}[device_pointer(a) for a in arrays]" in src
+
+
 def test_blocks_are_balanced():
     """a coarse syntax check: every block opener of the file has its `end` (strings and comments stripped)"""
     src = open(JL).read()
