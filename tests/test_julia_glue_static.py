@@ -109,6 +109,30 @@ def test_every_ccall_matches_the_c_prototype():
         assert needed in seen, f"{needed} is never ccall'ed from TripolarHIP.jl"
 
 
+def test_integer_arguments_of_every_ccall_sit_under_the_right_parameter_name():
+    """Types cannot tell Ny from Nz or rank from nranks: for every C parameter with one of these NAMES the Julia call must pass the value of
+    the same meaning at that position (a swapped pair of Cints would compile, run and fill the wrong rows)."""
+    src = open(JL).read()
+    protos = c_prototypes()
+    expect = {"Nx": {"Nx", "size(grid, 1)"}, "Ny": {"Ny"}, "Nz": {"Nz"}, "Hx": {"Hx", "halo_size(grid)[1]"}, "Hy": {"Hy", "halo_size(grid)[2]"},
+              "Hz": {"Hz"}, "rank": {"comm.rank", "rank"}, "nranks": {"comm.nranks", "nranks"}, "nfields": {"length(fs)", "nfields"},
+              "kstart": {"1"}, "kend": {"Nz"}, "north_is_zipper": {"1"}, "fields_per_stage": {"fps"},
+              "xloc": {"xloc"}, "yloc": {"yloc"}, "sign": {"sgn"}, "to_native": {"to_native ? 1 : 0"},
+              "send_south": {"bp[1]"}, "send_north": {"bp[2]"}, "recv_south": {"bp[3]"}, "recv_north": {"bp[4]"}}
+    checked = 0
+    for m in re.finditer(r"ccall\(\(:(tpg_[a-z0-9_]+),\s*libtripolar\)", src):
+        end = balanced(src, src.index("(", m.start()))
+        args = split_top(src[src.index("(", m.start()) + 1:end - 1])
+        values = [" ".join(v.split()) for v in args[3:]]
+        _, params = protos[m.group(1)]
+        for pos, (ct, val) in enumerate(zip(params, values)):
+            pname = re.sub(r"\[\]", "", ct.split()[-1]).lstrip("*")
+            if pname in expect:
+                assert val in expect[pname], f"{m.group(1)}: parameter {pos + 1} `{pname}` receives `{val}`"
+                checked += 1
+    assert checked >= 100, checked
+
+
 def test_struct_layout_matches_tpg_params():
     """the Julia mirror of struct tpg_params lists the same fields with the same widths, in the same order"""
     src = open(JL).read()
