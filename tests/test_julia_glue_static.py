@@ -204,6 +204,17 @@ def test_the_twenty_arrays_are_taken_in_the_order_of_enum_tpg_array():
     assert "arrays = [device_array(arch, FT, Nλ + 2Hλ, ny + 2Hφ) for _ in 1:20]" in src and "ptrs = Ptr{Cvoid}[device_pointer(a) for a in arrays]" in src
 
 
+def test_sign_policy_of_the_glue_is_the_reference_table():
+    """src/tripolar_grid_extensions.jl:49-53: +1 everywhere except the two velocity locations; and `regularize_field_boundary_conditions`
+    signs a field by its NAME (:u, :v -> -1), src/tripolar_grid_extensions.jl:32 -- the same table the Python host's tests execute"""
+    src = re.sub(r"#.*", "", open(JL).read())
+    methods = dict(re.findall(r"(?m)^sign\(([^)]*)\)\s*=\s*(-?\s*1)\s*$", src))
+    assert {k.replace(" ", ""): int(v.replace(" ", "")) for k, v in methods.items()} == \
+        {"LX,LY": 1, "::Type{Face},::Type{Center}": -1, "::Type{Center},::Type{Face}": -1}
+    assert "sgn = field_name == :u || field_name == :v ? -1 : 1" in src
+    assert src.count("ZipperBoundaryCondition(sign(LX, LY))") == 2           # serial and distributed Field constructors
+
+
 def test_blocks_are_balanced():
     """a coarse syntax check: every block opener of the file has its `end` (strings and comments stripped)"""
     src = open(JL).read()
