@@ -242,7 +242,7 @@ def fill_step_config5(torch, osg, _lib, tlib, dev):
            "fill3d_modelled_line_ops": (zb // 128) + rows * 3, "fill3d_modelled_lines_per_ns": ((zb // 128) + rows * 3) / (t3 * 1e3),
            "fill3d_cold_modelled_lines_per_ns": ((zb // 128) + rows * 3) / (t3_cold * 1e3),
            "substep_fill_us_each": t2 / substeps}
-    del f3, f2, grid, ext, graph
+    del plan3, f3, f2, grid, ext, graph
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     return out
