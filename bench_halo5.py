@@ -39,15 +39,16 @@ def periodic_bytes(ny, nz, halo, nfields, s=8):
     return nfields * (ny + 2 * hy) * (nz + 2 * hz) * 2 * hx * 2 * s
 
 
-def headline_fill(torch, _lib, lib, tlib, dev, h, size=(3600, 1800, 75), reps=12):
-    """4-field fill and fold at `size`, halo (h, h, h), Float64, cold"""
+def headline_fill(torch, _lib, lib, tlib, dev, h, size=(3600, 1800, 75), reps=12, f32=False):
+    """4-field fill and fold at `size`, halo (h, h, h), Float64 (or Float32), cold"""
     from tools import testlib
     nx, ny, nz = size
     geom = (nx, ny, nz, h, h, h)
     n = len(SPECS)
-    fields = [torch.empty((nz + 2 * h, ny + 2 * h, nx + 2 * h), dtype=torch.float64, device=dev) for _ in SPECS]
+    tdt, ft, esz = (torch.float32, _lib.TPG_F32, 4) if f32 else (torch.float64, _lib.TPG_F64, 8)
+    fields = [torch.empty((nz + 2 * h, ny + 2 * h, nx + 2 * h), dtype=tdt, device=dev) for _ in SPECS]
     for fid, f in enumerate(fields):
-        testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0x5A10 + fid, 12345.0, *geom, _lib.TPG_F64, None))
+        testlib.check(tlib.tpg_fill_synthetic(f.data_ptr(), 0x5A10 + fid, 12345.0, *geom, ft, None))
     pt = _lib.ptr_table(fields)
     xl = (C.c_int8 * n)(*[s[1] for s in SPECS]); yl = (C.c_int8 * n)(*[s[2] for s in SPECS]); sg = (C.c_int32 * n)(*[s[3] for s in SPECS])
     stream = _lib.current_stream_ptr(dev)
@@ -65,20 +66,20 @@ def headline_fill(torch, _lib, lib, tlib, dev, h, size=(3600, 1800, 75), reps=12
         flush.sum()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.check(lib.tpg_fill_halo_regions_timed(pt, n, xl, yl, sg, *geom, 1, _lib.TPG_F64, stream, k0, k1))
+        _lib.check(lib.tpg_fill_halo_regions_timed(pt, n, xl, yl, sg, *geom, 1, ft, stream, k0, k1))
         e1.record()
         torch.cuda.synchronize()
         t_fill.append(e0.elapsed_time(e1)); t_first.append(kernel_ms())
         flush.sum()
-        _lib.check(lib.tpg_zipper_fill_timed(pt, n, xl, yl, sg, *geom, 1, nz, _lib.TPG_F64, stream, k0, k1))
+        _lib.check(lib.tpg_zipper_fill_timed(pt, n, xl, yl, sg, *geom, 1, nz, ft, stream, k0, k1))
         t_fold.append(kernel_ms())
     lib.tpg_event_destroy(k0); lib.tpg_event_destroy(k1)
     del fields, flush
     torch.cuda.empty_cache()
-    zb, pb = fold_bytes(nx, nz, h, SPECS), periodic_bytes(ny, nz, (h, h, h), n)
+    zb, pb = fold_bytes(nx, nz, h, SPECS, esz), periodic_bytes(ny, nz, (h, h, h), n, esz)
     med = lambda v: statistics.median(v[2:])
     fill, first, fold = med(t_fill), med(t_first), med(t_fold)
-    return {"size": list(size), "halo": [h, h, h], "fields": [s[0] for s in SPECS],
+    return {"size": list(size), "halo": [h, h, h], "fields": [s[0] for s in SPECS], "eltype": "Float32" if f32 else "Float64",
             "fill_ms": fill, "fill_first_kernel_ms": first, "fill_algorithmic_bytes": zb + pb,
             "fill_ns_per_algorithmic_KB": fill * 1e6 / ((zb + pb) / 1e3),
             "fill_frac_of_hbm_peak": (zb + pb) / (fill * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -144,6 +145,11 @@ def fill_step_halo5(torch, osg, _lib, lib, tlib, dev, config5=True):
     a, b = out["headline_halo5"], out["headline_halo4_same_method"]
     out["headline_time_per_byte_halo5_over_halo4"] = a["fill_ns_per_algorithmic_KB"] / b["fill_ns_per_algorithmic_KB"]
     out["headline_fold_time_per_byte_halo5_over_halo4"] = (a["fold_ms"] / a["fold_algorithmic_bytes"]) / (b["fold_ms"] / b["fold_algorithmic_bytes"])
+    # Float32: rows of 3610 elements are no 16-B rows (the GEN form with r = 1 outermost column per side)
+    a, b = headline_fill(torch, _lib, lib, tlib, dev, 5, f32=True), headline_fill(torch, _lib, lib, tlib, dev, 4, f32=True)
+    out["headline_float32"] = {"halo5": a, "halo4_same_method": b,
+                               "time_per_byte_halo5_over_halo4": a["fill_ns_per_algorithmic_KB"] / b["fill_ns_per_algorithmic_KB"],
+                               "fold_time_per_byte_halo5_over_halo4": (a["fold_ms"] / a["fold_algorithmic_bytes"]) / (b["fold_ms"] / b["fold_algorithmic_bytes"])}
     if config5:
         out["config5_halo5"] = config5_fills(torch, osg, _lib, tlib, dev, 5)
         out["config5_halo4_same_method"] = config5_fills(torch, osg, _lib, tlib, dev, 4)

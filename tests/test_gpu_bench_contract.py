@@ -84,6 +84,9 @@ def test_bench_prints_one_contract_line(gpu):
     assert a5["fill_algorithmic_bytes"] == 90720000 + 4 * 1810 * 85 * 160 and a5["fold_algorithmic_bytes"] == 90720000
     assert 0 < a5["fill_first_kernel_ms"] <= a5["fill_ms"] < a5["fill_first_kernel_ms"] + 0.03          # one launch, not two
     assert 0.7 < h5["headline_time_per_byte_halo5_over_halo4"] < 1.25 and 0.7 < h5["headline_fold_time_per_byte_halo5_over_halo4"] < 1.25
+    f32 = h5["headline_float32"]                                              # Float32 rows of 3610 elements are no 16-B rows: still one launch, no slower per byte
+    assert f32["halo5"]["eltype"] == "Float32" and 0.6 < f32["time_per_byte_halo5_over_halo4"] < 1.25 and 0.6 < f32["fold_time_per_byte_halo5_over_halo4"] < 1.25
+    assert f32["halo5"]["fill_first_kernel_ms"] > 0.6 * f32["halo5"]["fill_ms"]
     if "skipped" not in h5.get("config5_halo5", {"skipped": 1}):
         assert h5["config5_halo5"]["fields_GB"] > 164 and 0.7 < h5["config5_time_per_byte_halo5_over_halo4"] < 1.25
 
